@@ -1,0 +1,83 @@
+/*
+ * modes_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C11) of readsb's receive-side hot path, used solely as the
+ * checker for the HIP path (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg).
+ * Nothing under readsb_amd/ may include, link or call this.
+ *
+ * Parity pin: this restatement is validated message-for-message (and counter-for-counter)
+ * against the UNMODIFIED reference compiled into oracle/_ref/ref_harness, and against the
+ * golden fixtures under tests/golden/ that ref_harness produced (tests/test_oracle_*.py).
+ *
+ * Every function cites the reference file:line it follows (paths relative to the
+ * reference tree, Mictronics/readsb v3.9.0).
+ */
+#ifndef MODES_ORACLE_H
+#define MODES_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_BLOCK_SAMPLES 131072u /* MODES_MAG_BUF_SAMPLES, readsb.h:96-97 */
+#define ORC_TRAILING 326u         /* Modes.trailing_samples, readsb.c:196 */
+
+enum { ORC_UC8 = 0, ORC_SC16 = 1, ORC_SC16Q11 = 2 }; /* input_format_t, convert.h:29-32 */
+
+/* same on-disk layout as oracle/ref_harness.c struct rec (packed, 51 bytes) */
+#pragma pack(push, 1)
+typedef struct {
+    uint64_t ts;       /* timestampMsg, 12 MHz */
+    uint8_t msg[14];   /* first msgbits/8 bytes valid, rest zero */
+    uint8_t msgbits;   /* 56 / 112 / 16 (Mode A/C) */
+    uint8_t msgtype;   /* DF, or 32 for Mode A/C */
+    uint32_t crc;
+    int32_t correctedbits;
+    uint32_t addr;
+    int32_t score;
+    int32_t source;
+    uint32_t iid;
+    double signal;     /* signalLevel */
+} orc_msg;
+#pragma pack(pop)
+
+typedef struct {
+    uint64_t preambles, rejected_bad, rejected_unknown, accepted[3], modeac;
+} orc_stats;
+
+typedef struct {
+    uint32_t syndrome;
+    int32_t errors;
+    int8_t bit[2];
+    uint16_t pad;
+} orc_errorinfo; /* struct errorinfo, crc.h:32-38 */
+
+typedef struct orc_ctx orc_ctx;
+
+orc_ctx *orc_create(int format, int dc_filter, int nfix, int modeac);
+void orc_destroy(orc_ctx *c);
+void orc_reset(orc_ctx *c); /* filter, converter state, stats, stream position */
+
+/* whole-stream run in the sdr_ifile.c block model; returns number of messages (may exceed cap;
+ * only the first cap are stored) */
+size_t orc_run_stream(orc_ctx *c, const void *iq, uint64_t nsamples, orc_msg *out, size_t cap);
+void orc_get_stats(const orc_ctx *c, orc_stats *st);
+
+/* pieces, for unit tests */
+void orc_convert(orc_ctx *c, const void *iq, uint16_t *mag, unsigned nsamples, double *mean_level, double *mean_power);
+uint32_t orc_checksum(const uint8_t *msg, int bits);
+const orc_errorinfo *orc_diagnose(const orc_ctx *c, uint32_t syndrome, int bits);
+int orc_table_size(const orc_ctx *c, int bits);
+const orc_errorinfo *orc_table(const orc_ctx *c, int bits);
+int orc_score(orc_ctx *c, const uint8_t *msg, int validbits);
+void orc_filter_add(orc_ctx *c, uint32_t addr);
+int orc_filter_test(const orc_ctx *c, uint32_t addr);
+const uint16_t *orc_uc8_lut(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

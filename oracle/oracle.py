@@ -1,0 +1,224 @@
+"""ctypes front-end for the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; nothing under readsb_amd/ does.  Two checkers live here:
+
+* ``Oracle``     -- oracle/libmodes_oracle.so, our plain-C restatement (modes_oracle.c).
+* ``RefHarness`` -- oracle/_ref/ref_harness, the unmodified reference compiled by
+  oracle/Makefile (present only where it was built; it travels to the GPU box as a binary).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libmodes_oracle.so")
+REF_BIN = os.path.join(HERE, "_ref", "ref_harness")
+
+FORMATS = {"UC8": 0, "SC16": 1, "SC16Q11": 2}
+
+# must match struct rec (ref_harness.c) and orc_msg (modes_oracle.h): packed, 56 bytes
+REC_DTYPE = np.dtype([
+    ("ts", "<u8"), ("msg", "u1", (14,)), ("msgbits", "u1"), ("msgtype", "u1"),
+    ("crc", "<u4"), ("correctedbits", "<i4"), ("addr", "<u4"), ("score", "<i4"),
+    ("source", "<i4"), ("iid", "<u4"), ("signal", "<f8"),
+])
+assert REC_DTYPE.itemsize == 56
+
+STAT_NAMES = ("preambles", "rejected_bad", "rejected_unknown", "accepted0", "accepted1", "accepted2", "modeac")
+
+ERRINFO_DTYPE = np.dtype([("syndrome", "<u4"), ("errors", "<i4"), ("bit", "i1", (2,)), ("pad", "<u2")])
+
+
+def build() -> None:
+    subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+def _lib():
+    if not os.path.exists(LIB):
+        build()
+    lib = C.CDLL(LIB)
+    lib.orc_create.restype = C.c_void_p
+    lib.orc_create.argtypes = [C.c_int] * 4
+    lib.orc_destroy.argtypes = [C.c_void_p]
+    lib.orc_reset.argtypes = [C.c_void_p]
+    lib.orc_run_stream.restype = C.c_size_t
+    lib.orc_run_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]
+    lib.orc_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_convert.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
+    lib.orc_checksum.restype = C.c_uint32
+    lib.orc_checksum.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_diagnose.restype = C.c_void_p
+    lib.orc_diagnose.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+    lib.orc_table_size.restype = C.c_int
+    lib.orc_table_size.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_table.restype = C.c_void_p
+    lib.orc_table.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_score.restype = C.c_int
+    lib.orc_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.orc_filter_add.argtypes = [C.c_void_p, C.c_uint32]
+    lib.orc_filter_test.restype = C.c_int
+    lib.orc_filter_test.argtypes = [C.c_void_p, C.c_uint32]
+    lib.orc_uc8_lut.restype = C.c_void_p
+    return lib
+
+
+def iq_bytes(iq: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+
+
+class Oracle:
+    def __init__(self, fmt="UC8", dc_filter=False, nfix=1, modeac=False):
+        self.lib = _lib()
+        self.fmt = fmt
+        self.bps = 2 if fmt == "UC8" else 4
+        self.h = self.lib.orc_create(FORMATS[fmt], int(dc_filter), int(nfix), int(modeac))
+        if not self.h:
+            raise ValueError("no suitable converter")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.lib.orc_reset(self.h)
+
+    def run_stream(self, iq: np.ndarray):
+        """-> (messages as REC_DTYPE array, stats dict)"""
+        raw = iq_bytes(iq)
+        n = raw.size // self.bps
+        cap = max(1024, n // 100)
+        while True:
+            out = np.zeros(cap, dtype=REC_DTYPE)
+            self.reset()
+            got = self.lib.orc_run_stream(self.h, raw.ctypes.data, n, out.ctypes.data, cap)
+            if got <= cap:
+                break
+            cap = got
+        st = np.zeros(7, dtype=np.uint64)
+        self.lib.orc_get_stats(self.h, st.ctypes.data)
+        return out[:got].copy(), dict(zip(STAT_NAMES, (int(x) for x in st)))
+
+    def convert(self, iq: np.ndarray):
+        raw = iq_bytes(iq)
+        n = raw.size // self.bps
+        mag = np.zeros(n, dtype=np.uint16)
+        ml, mp = C.c_double(), C.c_double()
+        self.lib.orc_convert(self.h, raw.ctypes.data, mag.ctypes.data, n, C.byref(ml), C.byref(mp))
+        return mag, ml.value, mp.value
+
+    def checksum(self, msg: bytes) -> int:
+        buf = (C.c_uint8 * len(msg)).from_buffer_copy(msg)
+        return self.lib.orc_checksum(buf, len(msg) * 8)
+
+    def table(self, bits: int) -> np.ndarray:
+        n = self.lib.orc_table_size(self.h, bits)
+        if n == 0:
+            return np.zeros(0, dtype=ERRINFO_DTYPE)
+        p = self.lib.orc_table(self.h, bits)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n * 12,)).view(ERRINFO_DTYPE).copy()
+
+    def score(self, msg: bytes, validbits: int) -> int:
+        buf = (C.c_uint8 * 14)(*(list(msg) + [0] * (14 - len(msg))))
+        return self.lib.orc_score(self.h, buf, validbits)
+
+    def filter_add(self, addr: int):
+        self.lib.orc_filter_add(self.h, addr)
+
+    def filter_test(self, addr: int) -> bool:
+        return bool(self.lib.orc_filter_test(self.h, addr))
+
+    def uc8_lut(self) -> np.ndarray:
+        p = self.lib.orc_uc8_lut()
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint16)), shape=(65536,)).copy()
+
+
+class RefHarness:
+    """The unmodified reference, run as a child process on a temp file."""
+
+    @staticmethod
+    def available() -> bool:
+        return os.access(REF_BIN, os.X_OK)
+
+    @staticmethod
+    def demod(iq: np.ndarray, fmt="UC8", nfix=1, modeac=False, dc_filter=False):
+        with tempfile.TemporaryDirectory() as d:
+            fin, fout = os.path.join(d, "in.iq"), os.path.join(d, "out.bin")
+            iq_bytes(iq).tofile(fin)
+            subprocess.run([REF_BIN, "demod", fmt, str(int(nfix)), str(int(modeac)), str(int(dc_filter)), fin, fout],
+                           check=True, stderr=subprocess.DEVNULL)
+            raw = np.fromfile(fout, dtype=np.uint8)
+        hdr = raw[:64].view("<u8")
+        recs = raw[64:].view(REC_DTYPE)
+        assert recs.size == int(hdr[0])
+        return recs.copy(), dict(zip(STAT_NAMES, (int(x) for x in hdr[1:8])))
+
+    @staticmethod
+    def convert(iq: np.ndarray, fmt="UC8", dc_filter=False, chunk=131072):
+        with tempfile.TemporaryDirectory() as d:
+            fin, fout = os.path.join(d, "in.iq"), os.path.join(d, "out.bin")
+            iq_bytes(iq).tofile(fin)
+            subprocess.run([REF_BIN, "convert", fmt, str(int(dc_filter)), str(chunk), fin, fout], check=True)
+            raw = np.fromfile(fout, dtype=np.uint8)
+        total, ncalls = (int(x) for x in raw[:16].view("<u8"))
+        mag = raw[16:16 + 2 * total].view("<u2").copy()
+        means = raw[16 + 2 * total:].view("<f8").reshape(ncalls, 2).copy()
+        return mag, means
+
+    @staticmethod
+    def crctab(nfix: int):
+        with tempfile.TemporaryDirectory() as d:
+            fout = os.path.join(d, "out.bin")
+            subprocess.run([REF_BIN, "crctab", str(nfix), fout], check=True, stderr=subprocess.DEVNULL)
+            raw = np.fromfile(fout, dtype=np.uint8)
+        pos, tabs = 0, {}
+        for bits in (56, 112):
+            n = int(raw[pos:pos + 4].view("<u4")[0])
+            pos += 4
+            tabs[bits] = raw[pos:pos + 16 * n].view("<i4").reshape(n, 4).copy()
+            pos += 16 * n
+        ka = raw[pos:pos + 8].view("<u4").copy()
+        return tabs, ka
+
+    @staticmethod
+    def time(path: str, fmt="UC8", nfix=1, modeac=False, dc_filter=False, reps=1) -> dict:
+        out = subprocess.run([REF_BIN, "time", fmt, str(int(nfix)), str(int(modeac)), str(int(dc_filter)), path, str(reps)],
+                             check=True, capture_output=True, text=True).stdout
+        return json.loads(out.strip().splitlines()[-1])
+
+
+def normalise(recs: np.ndarray) -> np.ndarray:
+    """Mask the two fields that the reference's downstream field decode rewrites for DF18
+    (mode_s.c:1379-1428, decodeExtendedSquitter: addr |= MODES_NON_ICAO_ADDRESS, source =
+    TISB/ADSR).  That decode is outside the hot path; every other field is compared bit for bit."""
+    out = recs.copy()
+    df18 = out["msgtype"] == 18
+    out["addr"][df18] = 0
+    out["source"][df18] = 0
+    return out
+
+
+def first_mismatch(a: np.ndarray, b: np.ndarray):
+    """None if the two message lists are identical (after normalise), else a description."""
+    a, b = normalise(a), normalise(b)
+    n = min(a.size, b.size)
+    for name in REC_DTYPE.names:
+        x, y = a[name][:n], b[name][:n]
+        if n == 0:
+            break
+        bad = np.nonzero((x != y).reshape(n, -1).any(axis=1))[0]
+        if bad.size:
+            i = int(bad[0])
+            return f"message {i} field {name}: {a[i]} != {b[i]} ({bad.size} differ)"
+    if a.size != b.size:
+        return f"message count {a.size} != {b.size}"
+    return None

@@ -1,0 +1,268 @@
+/*
+ * ref_harness.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * A single-threaded driver around the UNMODIFIED reference objects
+ * (/root/reference/{convert,demod_2400,mode_s,crc,icao_filter,mode_ac,...}.c,
+ * compiled where they lie by oracle/Makefile into oracle/_ref/).  It replaces
+ * only readsb.c's main(): it reproduces modesInit (readsb.c:187-251) and the
+ * block/overlap logic of ifileRun (sdr_ifile.c:184-228) on one thread and
+ * captures every message the reference hands to useModesMessage through
+ * -Wl,--wrap=useModesMessage (recipe: SURVEY.md Appendix C).
+ *
+ * icaoFilterExpire() is never called, so runs are deterministic
+ * (SURVEY.md Appendix B.2).
+ *
+ * Sub-commands:
+ *   demod   <fmt> <nfix> <modeac> <dcfilter> <in.iq> <out.bin>   message list + stats
+ *   convert <fmt> <dcfilter> <chunk> <in.iq> <out.bin>           magnitudes + per-call means
+ *   crctab  <nfix> <out.bin>                                     syndrome -> errorinfo, all 2^24 syndromes folded to a digest + table dump
+ *   time    <fmt> <nfix> <modeac> <dcfilter> <in.iq> <reps>      prints seconds of convert+demod (CPU baseline, kind="reference")
+ */
+#include "readsb.h"
+#include <inttypes.h>
+
+struct _Modes Modes;
+
+void receiverPositionChanged(float lat, float lon, float alt) {
+    (void) lat; (void) lon; (void) alt;
+}
+
+/* on-disk record; must match oracle/oracle.py REC_DTYPE */
+struct rec {
+    uint64_t ts;
+    uint8_t msg[14];
+    uint8_t msgbits;
+    uint8_t msgtype;
+    uint32_t crc;
+    int32_t correctedbits;
+    uint32_t addr;
+    int32_t score;
+    int32_t source;
+    uint32_t iid;
+    double signal;
+} __attribute__((packed));
+
+static struct rec *recs;
+static size_t nrecs, caprecs;
+static int capture = 1;
+
+void __wrap_useModesMessage(struct modesMessage *mm) {
+    if (!capture)
+        return;
+    if (nrecs == caprecs) {
+        caprecs = caprecs ? caprecs * 2 : 4096;
+        recs = realloc(recs, caprecs * sizeof (*recs));
+    }
+    struct rec *r = &recs[nrecs++];
+    memset(r, 0, sizeof (*r));
+    r->ts = mm->timestampMsg;
+    memcpy(r->msg, mm->msg, (mm->msgbits + 7) / 8);
+    r->msgbits = mm->msgbits;
+    r->msgtype = mm->msgtype;
+    r->crc = mm->crc;
+    r->correctedbits = mm->correctedbits;
+    r->addr = mm->addr;
+    r->score = mm->score;
+    r->source = mm->source;
+    r->iid = mm->IID;
+    r->signal = mm->signalLevel;
+}
+
+static input_format_t parse_fmt(const char *s) {
+    if (!strcasecmp(s, "uc8")) return INPUT_UC8;
+    if (!strcasecmp(s, "sc16")) return INPUT_SC16;
+    if (!strcasecmp(s, "sc16q11")) return INPUT_SC16Q11;
+    fprintf(stderr, "bad format %s\n", s);
+    exit(2);
+}
+
+static void *slurp(const char *path, size_t *len) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { perror(path); exit(2); }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    void *p = malloc(n ? n : 1);
+    if (fread(p, 1, n, f) != (size_t) n) { perror("read"); exit(2); }
+    fclose(f);
+    *len = n;
+    return p;
+}
+
+static void init_modes(int nfix, int modeac, int dcfilter) {
+    memset(&Modes, 0, sizeof (Modes));
+    Modes.sample_rate = 2400000.0;
+    Modes.nfix_crc = nfix;
+    Modes.check_crc = 1;
+    Modes.mode_ac = modeac;
+    Modes.dc_filter = dcfilter;
+    Modes.quiet = 1;
+    Modes.trailing_samples = (MODES_PREAMBLE_US + MODES_LONG_MSG_BITS + 16) * 1e-6 * Modes.sample_rate;
+    modesChecksumInit(Modes.nfix_crc);
+    icaoFilterInit();
+    modeACInit();
+}
+
+/* the ifileRun block loop, single threaded, two alternating mag_bufs */
+static void run_stream(input_format_t fmt, const uint8_t *iq, size_t nbytes, int modeac) {
+    unsigned bps = (fmt == INPUT_UC8) ? 2 : 4;
+    struct converter_state *st = NULL;
+    iq_convert_fn conv = init_converter(fmt, Modes.sample_rate, Modes.dc_filter, &st);
+    if (!conv) exit(2);
+
+    struct mag_buf bufs[2];
+    memset(bufs, 0, sizeof (bufs));
+    for (int i = 0; i < 2; ++i)
+        bufs[i].data = calloc(MODES_MAG_BUF_SAMPLES + Modes.trailing_samples, sizeof (uint16_t));
+
+    size_t total = nbytes / bps, pos = 0;
+    uint64_t sampleCounter = 0;
+    int cur = 0, eof = 0;
+    void *readbuf = malloc(MODES_MAG_BUF_SAMPLES * bps);
+    while (!eof) {
+        struct mag_buf *outbuf = &bufs[cur], *lastbuf = &bufs[cur ^ 1];
+        outbuf->sampleTimestamp = sampleCounter * 12e6 / Modes.sample_rate;
+        sampleCounter += MODES_MAG_BUF_SAMPLES;
+        if (lastbuf->length >= Modes.trailing_samples)
+            memcpy(outbuf->data, lastbuf->data + lastbuf->length, Modes.trailing_samples * sizeof (uint16_t));
+        else
+            memset(outbuf->data, 0, Modes.trailing_samples * sizeof (uint16_t));
+        outbuf->sysTimestamp = 0;
+
+        size_t want = MODES_MAG_BUF_SAMPLES, have = total - pos;
+        if (have < want) { want = have; eof = 1; }
+        memcpy(readbuf, iq + pos * bps, want * bps);
+        pos += want;
+        outbuf->length = want;
+        conv(readbuf, &outbuf->data[Modes.trailing_samples], want, st, &outbuf->mean_level, &outbuf->mean_power);
+
+        demodulate2400(outbuf);
+        if (modeac)
+            demodulate2400AC(outbuf);
+        cur ^= 1;
+    }
+    free(readbuf);
+    free(bufs[0].data);
+    free(bufs[1].data);
+    free(st); /* not cleanup_converter: it frees the global LUT without clearing it (convert.c:493-499) */
+}
+
+static int cmd_demod(int argc, char **argv) {
+    if (argc != 8) return 2;
+    input_format_t fmt = parse_fmt(argv[2]);
+    int nfix = atoi(argv[3]), modeac = atoi(argv[4]), dc = atoi(argv[5]);
+    size_t nbytes;
+    uint8_t *iq = slurp(argv[6], &nbytes);
+    init_modes(nfix, modeac, dc);
+    run_stream(fmt, iq, nbytes, modeac);
+    FILE *f = fopen(argv[7], "wb");
+    if (!f) { perror(argv[7]); return 2; }
+    uint64_t hdr[8] = {nrecs,
+        Modes.stats_current.demod_preambles,
+        Modes.stats_current.demod_rejected_bad,
+        Modes.stats_current.demod_rejected_unknown_icao,
+        Modes.stats_current.demod_accepted[0],
+        Modes.stats_current.demod_accepted[1],
+        Modes.stats_current.demod_accepted[2],
+        Modes.stats_current.demod_modeac};
+    fwrite(hdr, sizeof (hdr), 1, f);
+    fwrite(recs, sizeof (*recs), nrecs, f);
+    fclose(f);
+    return 0;
+}
+
+static int cmd_time(int argc, char **argv) {
+    if (argc != 8) return 2;
+    input_format_t fmt = parse_fmt(argv[2]);
+    int nfix = atoi(argv[3]), modeac = atoi(argv[4]), dc = atoi(argv[5]);
+    size_t nbytes;
+    uint8_t *iq = slurp(argv[6], &nbytes);
+    int reps = atoi(argv[7]);
+    capture = 0;
+    init_modes(nfix, modeac, dc);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int r = 0; r < reps; ++r)
+        run_stream(fmt, iq, nbytes, modeac);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    double s = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    unsigned bps = (fmt == INPUT_UC8) ? 2 : 4;
+    printf("{\"seconds\": %.6f, \"samples\": %" PRIu64 ", \"accepted\": %u}\n", s,
+            (uint64_t) (nbytes / bps) * reps,
+            Modes.stats_current.demod_accepted[0] + Modes.stats_current.demod_accepted[1] + Modes.stats_current.demod_accepted[2]);
+    return 0;
+}
+
+static int cmd_convert(int argc, char **argv) {
+    if (argc != 7) return 2;
+    input_format_t fmt = parse_fmt(argv[2]);
+    int dc = atoi(argv[3]);
+    unsigned chunk = atoi(argv[4]);
+    size_t nbytes;
+    uint8_t *iq = slurp(argv[5], &nbytes);
+    unsigned bps = (fmt == INPUT_UC8) ? 2 : 4;
+    size_t total = nbytes / bps;
+    struct converter_state *st = NULL;
+    iq_convert_fn conv = init_converter(fmt, 2400000.0, dc, &st);
+    if (!conv) return 2;
+    uint16_t *mag = malloc(total * 2 + 2);
+    size_t ncalls = (total + chunk - 1) / chunk;
+    double *means = calloc(ncalls * 2 + 2, sizeof (double));
+    size_t c = 0;
+    for (size_t pos = 0; pos < total; pos += chunk, ++c) {
+        unsigned n = (total - pos < chunk) ? (unsigned) (total - pos) : chunk;
+        conv(iq + pos * bps, mag + pos, n, st, &means[2 * c], &means[2 * c + 1]);
+    }
+    FILE *f = fopen(argv[6], "wb");
+    uint64_t hdr[2] = {total, ncalls};
+    fwrite(hdr, sizeof (hdr), 1, f);
+    fwrite(mag, 2, total, f);
+    fwrite(means, sizeof (double), ncalls * 2, f);
+    fclose(f);
+    return 0;
+}
+
+/* dump both syndrome tables by probing modesChecksumDiagnose over all 2^24 syndromes */
+static int cmd_crctab(int argc, char **argv) {
+    if (argc != 4) return 2;
+    int nfix = atoi(argv[2]);
+    modesChecksumInit(nfix);
+    FILE *f = fopen(argv[3], "wb");
+    for (int bits = 56; bits <= 112; bits += 56) {
+        uint32_t count = 0;
+        long at = ftell(f);
+        fwrite(&count, 4, 1, f);
+        for (uint32_t s = 1; s < (1u << 24); ++s) {
+            struct errorinfo *ei = modesChecksumDiagnose(s, bits);
+            if (ei) {
+                int32_t row[4] = {(int32_t) s, ei->errors, ei->bit[0], ei->bit[1]};
+                fwrite(row, sizeof (row), 1, f);
+                ++count;
+            }
+        }
+        long end = ftell(f);
+        fseek(f, at, SEEK_SET);
+        fwrite(&count, 4, 1, f);
+        fseek(f, end, SEEK_SET);
+    }
+    /* known answers for modesChecksum on fixed vectors */
+    uint8_t m[14];
+    for (int i = 0; i < 14; ++i) m[i] = (uint8_t) (i * 37 + 11);
+    uint32_t ka[2] = {modesChecksum(m, 56), modesChecksum(m, 112)};
+    fwrite(ka, sizeof (ka), 1, f);
+    fclose(f);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    int rc = 2;
+    if (argc >= 2) {
+        if (!strcmp(argv[1], "demod")) rc = cmd_demod(argc, argv);
+        else if (!strcmp(argv[1], "time")) rc = cmd_time(argc, argv);
+        else if (!strcmp(argv[1], "convert")) rc = cmd_convert(argc, argv);
+        else if (!strcmp(argv[1], "crctab")) rc = cmd_crctab(argc, argv);
+    }
+    if (rc == 2)
+        fprintf(stderr, "usage: see header of oracle/ref_harness.c\n");
+    return rc;
+}
