@@ -1,0 +1,197 @@
+/*
+ * readsb_amd.h -- C ABI of libreadsb_amd.so: an MI355X (gfx950) implementation of readsb's
+ * receive-side hot path (IQ -> magnitude -> Mode-S / Mode A/C demodulation -> CRC repair).
+ *
+ * Plain C, plain pointers and sizes; HIP stays behind this boundary.  Two groups:
+ *
+ *   1. The batched fast path (rsb_*): device- or host-resident IQ for a whole recording or a
+ *      stream of 131072-sample blocks in, the reference's message list out.  This is our own
+ *      entry (the reference has no batched call); what it replaces is the per-block loop
+ *      readsb.c:847-911 -> sdr_ifile.c:184-228 -> convert.c -> demod_2400.c:72-383 / :476-662.
+ *
+ *   2. Reference-signature drop-ins (include/readsb_dropin.h): init_converter / iq_convert_fn /
+ *      cleanup_converter, demodulate2400(struct mag_buf*), demodulate2400AC(struct mag_buf*),
+ *      modesChecksum*.
+ *
+ * All citations are file:line in Mictronics/readsb v3.9.0.
+ *
+ * Error behaviour mirrors the reference's (SURVEY.md section 8b "Errors"): no error codes on
+ * the data path of the drop-ins (NULL / false + a message on stderr at init); the rsb_* calls
+ * return 0 on success and a negative RSB_E* code otherwise, with rsb_last_error() for text.
+ * The library never falls back to a CPU implementation: without a usable HIP device every
+ * compute call fails with RSB_ENODEV.
+ */
+#ifndef READSB_AMD_H
+#define READSB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSB_BLOCK_SAMPLES 131072u /* MODES_MAG_BUF_SAMPLES, readsb.h:96-97 */
+#define RSB_TRAILING_SAMPLES 326u /* Modes.trailing_samples, readsb.c:196 */
+
+/* input_format_t, convert.h:29-32 */
+enum { RSB_UC8 = 0, RSB_SC16 = 1, RSB_SC16Q11 = 2 };
+
+enum {
+    RSB_OK = 0,
+    RSB_EINVAL = -1,   /* bad argument / unsupported combination */
+    RSB_ENODEV = -2,   /* no HIP device, or a HIP call failed */
+    RSB_ENOMEM = -3,
+    RSB_EOVERFLOW = -4,/* a device queue overflowed (raise rsb_config.queue_div); no partial results */
+    RSB_ESTATE = -5    /* call sequence error (collect without submit, unaligned stream position...) */
+};
+
+/* What --device-type ifile --iformat X [--dcfilter] [--fix|--no-fix|--aggressive] [--modeac] select
+ * (sdr_ifile.c:82-106, readsb.c:485-509, 538-540). */
+typedef struct rsb_config {
+    int32_t input_format;      /* RSB_UC8 / RSB_SC16 / RSB_SC16Q11 */
+    int32_t dc_filter;         /* --dcfilter: not yet available on the GPU path -> RSB_EINVAL */
+    int32_t fix_bits;          /* Modes.nfix_crc: 0 (--no-fix), 1 (--fix, default), 2 (--aggressive) */
+    int32_t mode_ac;           /* --modeac */
+    int32_t device;            /* HIP device ordinal */
+    uint32_t queue_div;        /* device queues hold max_batch_samples/queue_div candidates (0 -> 32) */
+    uint64_t max_batch_samples;/* largest nsamples a single rsb_submit will be given */
+} rsb_config;
+
+/* One decoded message: the fields of struct modesMessage (readsb.h:421-439) that the hot path
+ * itself produces.  Packed, 56 bytes. */
+#pragma pack(push, 1)
+typedef struct rsb_message {
+    uint64_t timestamp;     /* timestampMsg, 12 MHz: demod_2400.c:320 / :649 */
+    uint8_t msg[14];        /* corrected message, first msgbits/8 bytes (rest zero) */
+    uint8_t msgbits;        /* 56, 112, or 16 for Mode A/C (mode_ac.c:171) */
+    uint8_t msgtype;        /* DF, or 32 for Mode A/C (mode_ac.c:168) */
+    uint32_t crc;           /* mm->crc: syndrome before repair (mode_s.c:440) */
+    int32_t correctedbits;  /* mode_s.c:489,518 */
+    uint32_t addr;          /* as left by mode_s.c:424-562 / mode_ac.c:176 (before ES field decode) */
+    int32_t score;          /* scoreModesMessage result of the winning phase (demod_2400.c:325) */
+    int32_t source;         /* datasource_t as left by mode_s.c:464-543 / mode_ac.c:166 */
+    uint32_t iid;           /* DF11 interrogator id (mode_s.c:475) */
+    double signal_level;    /* demod_2400.c:342-354 */
+} rsb_message;
+#pragma pack(pop)
+
+/* Counters.  The demod_* members of struct stats (stats.h:62-71) are only exact when the context
+ * was created with RSB_FLAG_EXACT_STATS; messages/accepted[] are always exact. */
+typedef struct rsb_stats {
+    uint64_t samples_processed;
+    uint64_t demod_preambles, demod_rejected_bad, demod_rejected_unknown_icao;
+    uint64_t demod_accepted[3];
+    uint64_t demod_modeac;
+    uint64_t gated_offsets;     /* offsets passing the preamble gate (before the greedy skip) */
+    uint64_t live_candidates;   /* ... with at least one phase that is not "-2 under any filter" */
+    uint64_t survivors;         /* ... left after the filter-superset prune (replayed on the host) */
+    uint64_t modeac_candidates;
+} rsb_stats;
+
+/* Durations of the last rsb_submit, measured with HIP events on the submit stream. */
+typedef struct rsb_timing {
+    float scan_ms;      /* the fused convert+gate+slice+CRC kernel (dominant kernel) */
+    float prune_ms;     /* filter-superset prune + survivor re-slice */
+    float modeac_ms;    /* block statistics + Mode A/C kernel (0 if mode_ac off) */
+    float total_ms;     /* first kernel start to last kernel end */
+    float replay_ms;    /* host: sort + sequential replay of the last rsb_collect */
+} rsb_timing;
+
+typedef struct rsb_ctx rsb_ctx;
+
+/* One context = one receiver channel: its own stream position, ICAO filter (icao_filter.c) and
+ * device work buffers.  Replaces modesInit (readsb.c:187-251) + ifileOpen (sdr_ifile.c:115-160). */
+int rsb_create(const rsb_config *cfg, rsb_ctx **out);
+void rsb_destroy(rsb_ctx *ctx);
+
+/* Start a new recording: stream position 0, zero overlap (sdr_ifile.c:200-204), empty filter
+ * (icaoFilterInit, icao_filter.c:65-69), counters cleared. */
+int rsb_reset(rsb_ctx *ctx);
+
+/* icaoFilterAdd (icao_filter.c:71-95): what --show-only does at start-up (readsb.c:249-250). */
+int rsb_filter_add(rsb_ctx *ctx, uint32_t addr);
+/* One icaoFilterExpire flip (icao_filter.c:147-161) as an explicit event between submits; the
+ * reference drives it from wall-clock time, which a reproducible batch run cannot. */
+int rsb_filter_expire(rsb_ctx *ctx);
+
+/* Enqueue the scan of the next `nsamples` IQ samples of this channel, resident in device memory
+ * at `iq_dev` (2 bytes/sample for UC8, 4 for SC16/SC16Q11, interleaved I,Q as convert.c reads
+ * them), on HIP stream `stream` (a hipStream_t passed as void*, NULL = default stream).
+ * Asynchronous.  The stream position must be a multiple of RSB_BLOCK_SAMPLES at entry (every
+ * batch but the last of a recording is a whole number of blocks).  The buffer must stay valid
+ * until rsb_collect returns. */
+int rsb_submit(rsb_ctx *ctx, const void *iq_dev, uint64_t nsamples, void *stream);
+
+/* Wait for the submitted batch, replay the surviving candidates through the reference's
+ * sequential rules on the host and append the decoded messages, in the reference's emission
+ * order, to out[0..cap).  *n_out receives the number of messages of this batch (if it exceeds
+ * cap only the first cap are stored and RSB_EOVERFLOW is returned). */
+int rsb_collect(rsb_ctx *ctx, rsb_message *out, size_t cap, size_t *n_out);
+
+/* rsb_submit + rsb_collect */
+int rsb_process(rsb_ctx *ctx, const void *iq_dev, uint64_t nsamples, void *stream,
+                rsb_message *out, size_t cap, size_t *n_out);
+
+/* Same, from a host buffer (what ifileRun's read() fills, sdr_ifile.c:209-223): stages the IQ
+ * into a device buffer owned by the context first. */
+int rsb_process_host(rsb_ctx *ctx, const void *iq_host, uint64_t nsamples,
+                     rsb_message *out, size_t cap, size_t *n_out);
+
+int rsb_get_stats(const rsb_ctx *ctx, rsb_stats *st);
+int rsb_get_timing(const rsb_ctx *ctx, rsb_timing *t);
+const char *rsb_last_error(const rsb_ctx *ctx);
+const char *rsb_version(void);
+
+/* ---- stand-alone pieces of the path, for callers that bind them one by one -------------- */
+
+/* iq_convert_fn on device buffers (convert.c:63-423): nsamples IQ -> uint16 magnitudes.
+ * mean_level / mean_power may be NULL (convert.c:104-110). UC8 no-DC only returns exact means. */
+int rsb_convert_device(rsb_ctx *ctx, const void *iq_dev, void *mag_dev, uint64_t nsamples, void *stream,
+                       double *mean_level, double *mean_power);
+
+/* crc.h:40-44 on the host tables the context was built with. */
+uint32_t rsb_checksum(const uint8_t *msg, int bits);
+/* modesChecksumDiagnose: returns number of bit errors (0..2) and their positions, or -1 if the
+ * syndrome is not correctable with this context's fix_bits. */
+int rsb_diagnose(const rsb_ctx *ctx, uint32_t syndrome, int bits, int bitpos[2]);
+
+/* ---- host-only pieces (no device needed) ---------------------------------------------------- */
+
+/* The syndrome tables modesChecksumInit(fix_bits) builds (crc.c:353-378): number of entries for
+ * 56- / 112-bit frames, and entry `idx` in ascending syndrome order. */
+int rsb_crc_table_size(int fix_bits, int bits);
+int rsb_crc_table_entry(int fix_bits, int bits, int idx, uint32_t *syndrome, int *errors, int bitpos[2]);
+
+/* The 65536-entry UC8 magnitude table of convert.c:35-61, indexed by the 16-bit sample word. */
+const uint16_t *rsb_uc8_lut(void);
+
+/* A gated scan offset as the finalize kernel hands it to the replay: the five sliced trial
+ * messages (try_phase 4..8, demod_2400.c:179-286), how many bytes each holds (14, 7, or 1 when the
+ * slicer gave up, :272-285) and sum(mag^2) over 134 / 268 samples from S[g+19] (:345-351). */
+typedef struct rsb_candidate {
+    uint32_t g;            /* scan offset relative to the batch start */
+    uint8_t vbytes[5];
+    uint8_t pad;
+    uint8_t msg[5][14];
+    uint64_t pow134, pow268;
+} rsb_candidate;           /* 96 bytes */
+
+typedef struct rsb_ac_candidate {
+    uint32_t g;            /* f1_sample, relative to the batch start */
+    uint32_t f2_clock;     /* block-local 60 MHz clock of F2 (demod_2400.c:558) */
+    uint32_t modeac;       /* Gillham-reordered code (demod_2400.c:626-639) */
+} rsb_ac_candidate;
+
+/* The sequential half of the path on its own: score every candidate's phases against a fresh
+ * ICAO filter, pick the best (demod_2400.c:289-301), run the CRC part of decodeModesMessage,
+ * apply the greedy skips (:371, :659) per 131072-sample block, emit in the reference's order.
+ * Candidates may be any superset of the offsets the reference would accept, in any order.
+ * g0 = stream position of candidate offset 0 (a multiple of RSB_BLOCK_SAMPLES). */
+int rsb_host_replay(int fix_bits, uint64_t g0, const rsb_candidate *cands, size_t ncands,
+                    const rsb_ac_candidate *ac, size_t nac, rsb_message *out, size_t cap, size_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* READSB_AMD_H */

@@ -243,6 +243,10 @@ struct orc_ctx {
     /* message sink */
     orc_msg *out;
     size_t cap, nout;
+    orc_candidate *cand_out;
+    size_t cand_cap, ncand;
+    orc_ac_candidate *ac_out;
+    size_t ac_cap, nac;
     /* the two alternating slice buffers live across calls in the reference only as stack
      * garbage; we keep them zero-initialised per demod call (compared bytes are msgbits/8 only) */
 };
@@ -572,18 +576,13 @@ static int slice_bit(const uint16_t *p, int phase) {
     }
 }
 
-static void demod2400(orc_ctx *c, const uint16_t *m, uint32_t mlen, uint64_t sampleTimestamp) {
-    uint8_t msg1[14], msg2[14], *msg = msg1;
-    memset(msg1, 0, sizeof (msg1));
-    memset(msg2, 0, sizeof (msg2));
-
-    for (uint32_t j = 0; j < mlen; j++) {
-        const uint16_t *p = &m[j];
+/* demod_2400.c:109-172 */
+static int preamble_gate(const uint16_t *p) {
         int high;
         uint32_t base_signal, base_noise;
 
         if (!(p[0] < p[1] && p[12] > p[13])) /* :109 */
-            continue;
+            return 0;
         if (p[1] > p[2] && p[2] < p[3] && p[3] > p[4] && p[8] < p[9] && p[9] > p[10] && p[10] < p[11]) { /* :112-119 */
             high = (p[1] + p[3] + p[9] + p[11] + p[12]) / 4;
             base_signal = p[1] + p[3] + p[9];
@@ -605,41 +604,76 @@ static void demod2400(orc_ctx *c, const uint16_t *m, uint32_t mlen, uint64_t sam
             base_signal = p[4] + p[10] + p[12];
             base_noise = p[6] + p[7] + p[8];
         } else {
-            continue;
+            return 0;
         }
         if (base_signal * 2 < 3 * base_noise) /* :158 */
-            continue;
+            return 0;
         if (p[5] >= high || p[6] >= high || p[7] >= high || p[8] >= high || p[14] >= high ||
                 p[15] >= high || p[16] >= high || p[17] >= high || p[18] >= high) /* :162-172 */
+            return 0;
+        return 1;
+}
+
+/* demod_2400.c:179-286 for one trial phase, closed form: bit k is sliced at
+ * P = try_phase + 12k, sample 19 + P/5, correlator P%5. Returns bytes sliced (14, 7 or 1). */
+static int slice_message(const uint16_t *pre, int try_phase, uint8_t *msg) {
+    int bytelen = 14, i;
+    for (i = 0; i < bytelen; ++i) {
+        uint8_t b = 0;
+        for (int bit = 0; bit < 8; ++bit) {
+            int P = try_phase + 12 * (i * 8 + bit);
+            b = (uint8_t) ((b << 1) | slice_bit(&pre[19 + P / 5], P % 5));
+        }
+        msg[i] = b;
+        if (i == 0) { /* :272-285 */
+            switch (msg[0] >> 3) {
+                case 0: case 4: case 5: case 11:
+                    bytelen = 7;
+                    break;
+                case 16: case 17: case 18: case 20: case 21: case 24:
+                    break;
+                default:
+                    bytelen = 1;
+                    break;
+            }
+        }
+    }
+    return i;
+}
+
+static void demod2400(orc_ctx *c, const uint16_t *m, uint32_t mlen, uint64_t sampleTimestamp) {
+    uint8_t msg1[14], msg2[14], *msg = msg1;
+    memset(msg1, 0, sizeof (msg1));
+    memset(msg2, 0, sizeof (msg2));
+
+    for (uint32_t j = 0; j < mlen; j++) {
+        if (c->cand_out) { /* candidate dump mode: no scoring, no skipping */
+            if (preamble_gate(&m[j])) {
+                if (c->ncand < c->cand_cap) {
+                    orc_candidate *r = &c->cand_out[c->ncand];
+                    memset(r, 0, sizeof (*r));
+                    r->g = (uint32_t) (sampleTimestamp / 5 + j);
+                    for (int p = 0; p < 5; ++p)
+                        r->vbytes[p] = (uint8_t) slice_message(&m[j], p + 4, r->msg[p]);
+                    for (int k = 0; k < 268; ++k) {
+                        uint64_t v = (uint64_t) m[j + 19 + k] * m[j + 19 + k];
+                        r->pow268 += v;
+                        if (k < 134)
+                            r->pow134 += v;
+                    }
+                }
+                c->ncand++;
+            }
+            continue;
+        }
+        if (!preamble_gate(&m[j]))
             continue;
 
         c->stats.preambles++;
         uint8_t *bestmsg = NULL;
         int bestscore = -2, bestphase = -1;
         for (int try_phase = 4; try_phase <= 8; ++try_phase) { /* :179-301 */
-            /* closed form of the five unrolled byte tables (:193-269): bit k is sliced at
-             * P = try_phase + 12k, sample 19 + P/5, correlator P%5 */
-            int bytelen = 14, i;
-            for (i = 0; i < bytelen; ++i) {
-                uint8_t b = 0;
-                for (int bit = 0; bit < 8; ++bit) {
-                    int P = try_phase + 12 * (i * 8 + bit);
-                    b = (uint8_t) ((b << 1) | slice_bit(&m[j + 19 + P / 5], P % 5));
-                }
-                msg[i] = b;
-                if (i == 0) { /* :272-285 */
-                    switch (msg[0] >> 3) {
-                        case 0: case 4: case 5: case 11:
-                            bytelen = 7;
-                            break;
-                        case 16: case 17: case 18: case 20: case 21: case 24:
-                            break;
-                        default:
-                            bytelen = 1;
-                            break;
-                    }
-                }
-            }
+            int i = slice_message(&m[j], try_phase, msg);
             int score = orc_score(c, msg, i * 8);
             if (score > bestscore) { /* :290-300 */
                 bestmsg = msg;
@@ -754,6 +788,16 @@ static void demod2400AC(orc_ctx *c, const uint16_t *m, uint32_t mlen, uint64_t s
                 ((bits & 0x00080) ? 0x0400 : 0) | ((bits & 0x00040) ? 0x0004 : 0) |
                 ((bits & 0x00004) ? 0x0080 : 0);
 
+        if (c->ac_out) { /* candidate dump mode: every passing offset, no skip */
+            if (c->nac < c->ac_cap) {
+                c->ac_out[c->nac].g = (uint32_t) (sampleTimestamp / 5 + f1_sample);
+                c->ac_out[c->nac].f2_clock = f2_clock;
+                c->ac_out[c->nac].modeac = modeac;
+            }
+            c->nac++;
+            continue;
+        }
+
         orc_msg mm;
         memset(&mm, 0, sizeof (mm));
         mm.ts = sampleTimestamp + f2_clock / 5; /* :649 */
@@ -812,4 +856,29 @@ size_t orc_run_stream(orc_ctx *c, const void *iq, uint64_t nsamples, orc_msg *ou
     free(buf[1]);
     c->out = NULL;
     return c->nout;
+}
+
+size_t orc_gated_candidates(orc_ctx *c, const void *iq, uint64_t nsamples, orc_candidate *out, size_t cap) {
+    int modeac = c->modeac;
+    c->modeac = 0;
+    c->cand_out = out ? out : (orc_candidate *) (uintptr_t) 1;
+    c->cand_cap = out ? cap : 0;
+    c->ncand = 0;
+    orc_run_stream(c, iq, nsamples, NULL, 0);
+    c->cand_out = NULL;
+    c->modeac = modeac;
+    return c->ncand;
+}
+
+size_t orc_ac_candidates(orc_ctx *c, const void *iq, uint64_t nsamples, orc_ac_candidate *out, size_t cap) {
+    int modeac = c->modeac;
+    c->modeac = 1;
+    c->ac_out = out ? out : (orc_ac_candidate *) (uintptr_t) 1;
+    c->ac_cap = out ? cap : 0;
+    c->nac = 0;
+    orc_msg dummy;
+    orc_run_stream(c, iq, nsamples, &dummy, 0);
+    c->ac_out = NULL;
+    c->modeac = modeac;
+    return c->nac;
 }

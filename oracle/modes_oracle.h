@@ -77,6 +77,24 @@ void orc_filter_add(orc_ctx *c, uint32_t addr);
 int orc_filter_test(const orc_ctx *c, uint32_t addr);
 const uint16_t *orc_uc8_lut(void);
 
+/* Every scan offset of the stream that passes the preamble gate (demod_2400.c:109-172), with the
+ * five sliced trial messages and the two signal-power sums -- i.e. what the greedy loop would see
+ * if it never skipped.  Layout = the product's 96-byte candidate record, so tests can push the
+ * oracle's candidates through the product's host replay without a GPU. */
+typedef struct {
+    uint32_t g;
+    uint8_t vbytes[5];
+    uint8_t pad;
+    uint8_t msg[5][14];
+    uint64_t pow134, pow268;
+} orc_candidate;
+size_t orc_gated_candidates(orc_ctx *c, const void *iq, uint64_t nsamples, orc_candidate *out, size_t cap);
+/* Mode A/C offsets passing every per-offset test (demod_2400.c:535-622), before the skip of :659 */
+typedef struct {
+    uint32_t g, f2_clock, modeac;
+} orc_ac_candidate;
+size_t orc_ac_candidates(orc_ctx *c, const void *iq, uint64_t nsamples, orc_ac_candidate *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,206 @@
+"""readsb_amd -- MI355X-native receive-side hot path of readsb behind a C ABI.
+
+The product is ``libreadsb_amd.so`` (HIP kernels + host replay, see include/readsb_amd.h).
+This package is only the ctypes plumbing the tests and bench.py use to call that C ABI; it
+holds no algorithmic code and has no CPU fallback: if the shared library is missing, or no
+HIP device is present, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libreadsb_amd.so")
+
+FORMATS = {"UC8": 0, "SC16": 1, "SC16Q11": 2}
+BLOCK = 131072
+TRAILING = 326
+
+# rsb_message, packed (include/readsb_amd.h)
+MSG_DTYPE = np.dtype([
+    ("ts", "<u8"), ("msg", "u1", (14,)), ("msgbits", "u1"), ("msgtype", "u1"),
+    ("crc", "<u4"), ("correctedbits", "<i4"), ("addr", "<u4"), ("score", "<i4"),
+    ("source", "<i4"), ("iid", "<u4"), ("signal", "<f8"),
+])
+CAND_DTYPE = np.dtype([("g", "<u4"), ("vbytes", "u1", (5,)), ("pad", "u1"), ("msg", "u1", (5, 14)),
+                       ("pow134", "<u8"), ("pow268", "<u8")])
+AC_DTYPE = np.dtype([("g", "<u4"), ("f2_clock", "<u4"), ("modeac", "<u4")])
+assert MSG_DTYPE.itemsize == 56 and CAND_DTYPE.itemsize == 96 and AC_DTYPE.itemsize == 12
+
+
+class Config(C.Structure):
+    _fields_ = [("input_format", C.c_int32), ("dc_filter", C.c_int32), ("fix_bits", C.c_int32), ("mode_ac", C.c_int32),
+                ("device", C.c_int32), ("queue_div", C.c_uint32), ("max_batch_samples", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples_processed", C.c_uint64), ("demod_preambles", C.c_uint64), ("demod_rejected_bad", C.c_uint64),
+                ("demod_rejected_unknown_icao", C.c_uint64), ("demod_accepted", C.c_uint64 * 3), ("demod_modeac", C.c_uint64),
+                ("gated_offsets", C.c_uint64), ("live_candidates", C.c_uint64), ("survivors", C.c_uint64),
+                ("modeac_candidates", C.c_uint64)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("scan_ms", C.c_float), ("prune_ms", C.c_float), ("modeac_ms", C.c_float), ("total_ms", C.c_float),
+                ("replay_ms", C.c_float)]
+
+
+# every symbol include/readsb_amd.h declares: name -> (restype, argtypes)
+_VP, _SZ = C.c_void_p, C.c_size_t
+SYMBOLS = {
+    "rsb_create": (C.c_int, [C.POINTER(Config), C.POINTER(_VP)]),
+    "rsb_destroy": (None, [_VP]),
+    "rsb_reset": (C.c_int, [_VP]),
+    "rsb_filter_add": (C.c_int, [_VP, C.c_uint32]),
+    "rsb_filter_expire": (C.c_int, [_VP]),
+    "rsb_submit": (C.c_int, [_VP, _VP, C.c_uint64, _VP]),
+    "rsb_collect": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
+    "rsb_process": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP, _SZ, C.POINTER(_SZ)]),
+    "rsb_process_host": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
+    "rsb_get_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
+    "rsb_get_timing": (C.c_int, [_VP, C.POINTER(Timing)]),
+    "rsb_last_error": (C.c_char_p, [_VP]),
+    "rsb_version": (C.c_char_p, []),
+    "rsb_convert_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64, _VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rsb_checksum": (C.c_uint32, [_VP, C.c_int]),
+    "rsb_diagnose": (C.c_int, [_VP, C.c_uint32, C.c_int, C.POINTER(C.c_int * 2)]),
+    "rsb_crc_table_size": (C.c_int, [C.c_int, C.c_int]),
+    "rsb_crc_table_entry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int * 2)]),
+    "rsb_uc8_lut": (_VP, []),
+    "rsb_host_replay": (C.c_int, [C.c_int, C.c_uint64, _VP, _SZ, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
+}
+
+_lib = None
+
+
+def lib():
+    """The C ABI. Raises if libreadsb_amd.so has not been built (python __graft_entry__.py builds it)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C readsb_amd/csrc` "
+                               "(there is no CPU fallback for the HIP path)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class RsbError(RuntimeError):
+    pass
+
+
+class Channel:
+    """One receiver channel (rsb_ctx)."""
+
+    def __init__(self, fmt="UC8", fix_bits=1, mode_ac=False, dc_filter=False, device=0, max_batch_samples=1 << 24, queue_div=0):
+        self.l = lib()
+        self.fmt = fmt
+        self.bps = 2 if fmt == "UC8" else 4
+        cfg = Config(FORMATS[fmt], int(dc_filter), int(fix_bits), int(mode_ac), int(device), int(queue_div), int(max_batch_samples))
+        h = _VP()
+        rc = self.l.rsb_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise RsbError(f"rsb_create failed: {rc}")
+        self.h = h
+        self.max_batch = max_batch_samples
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.l.rsb_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RsbError(f"{what}: rc={rc}: {self.l.rsb_last_error(self.h).decode()}")
+
+    def reset(self):
+        self._check(self.l.rsb_reset(self.h), "rsb_reset")
+
+    def filter_add(self, addr):
+        self._check(self.l.rsb_filter_add(self.h, addr), "rsb_filter_add")
+
+    def submit(self, dev_ptr: int, nsamples: int, stream: int = 0):
+        self._check(self.l.rsb_submit(self.h, dev_ptr, nsamples, stream), "rsb_submit")
+
+    def collect(self, cap: int = 1 << 16) -> np.ndarray:
+        out = np.zeros(cap, dtype=MSG_DTYPE)
+        n = _SZ()
+        rc = self.l.rsb_collect(self.h, out.ctypes.data, cap, C.byref(n))
+        if rc == -4 and n.value > cap:
+            raise RsbError(f"rsb_collect: {n.value} messages exceed cap {cap}")
+        self._check(rc, "rsb_collect")
+        return out[:n.value]
+
+    def process_host(self, iq: np.ndarray, cap: int | None = None) -> np.ndarray:
+        raw = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+        ns = raw.size // self.bps
+        cap = cap or max(4096, ns // 64)
+        out = np.zeros(cap, dtype=MSG_DTYPE)
+        n = _SZ()
+        self._check(self.l.rsb_process_host(self.h, raw.ctypes.data, ns, out.ctypes.data, cap, C.byref(n)), "rsb_process_host")
+        return out[:n.value].copy()
+
+    def process_stream_host(self, iq: np.ndarray, batch_blocks: int) -> np.ndarray:
+        """Feed a recording in batches of batch_blocks x 131072 samples (last one partial)."""
+        raw = np.ascontiguousarray(iq).view(np.uint8).reshape(-1, self.bps)
+        step = batch_blocks * BLOCK
+        parts = []
+        pos = 0
+        while True:
+            chunk = raw[pos:pos + step]
+            parts.append(self.process_host(chunk))
+            pos += step
+            if chunk.shape[0] < step:  # the reference also runs a final (possibly empty) block at EOF
+                break
+        return np.concatenate(parts)
+
+    def stats(self) -> dict:
+        st = Stats()
+        self.l.rsb_get_stats(self.h, C.byref(st))
+        d = {k: getattr(st, k) for k, _ in Stats._fields_ if k != "demod_accepted"}
+        d["demod_accepted"] = list(st.demod_accepted)
+        return d
+
+    def timing(self) -> dict:
+        t = Timing()
+        self.l.rsb_get_timing(self.h, C.byref(t))
+        return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+
+def host_replay(fix_bits: int, cands: np.ndarray, ac: np.ndarray | None = None, g0: int = 0) -> np.ndarray:
+    l = lib()
+    cands = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+    ac = np.zeros(0, dtype=AC_DTYPE) if ac is None else np.ascontiguousarray(ac, dtype=AC_DTYPE)
+    cap = cands.size + ac.size + 1
+    out = np.zeros(cap, dtype=MSG_DTYPE)
+    n = _SZ()
+    rc = l.rsb_host_replay(fix_bits, g0, cands.ctypes.data, cands.size, ac.ctypes.data, ac.size, out.ctypes.data, cap, C.byref(n))
+    if rc != 0:
+        raise RsbError(f"rsb_host_replay rc={rc}")
+    return out[:n.value].copy()
+
+
+def crc_table(fix_bits: int, bits: int) -> np.ndarray:
+    """rows of (syndrome, errors, bit0, bit1)"""
+    l = lib()
+    n = l.rsb_crc_table_size(fix_bits, bits)
+    rows = np.zeros((n, 4), dtype=np.int64)
+    syn, err, pos = C.c_uint32(), C.c_int(), (C.c_int * 2)()
+    for i in range(n):
+        l.rsb_crc_table_entry(fix_bits, bits, i, C.byref(syn), C.byref(err), C.byref(pos))
+        rows[i] = (syn.value, err.value, pos[0], pos[1])
+    return rows
+
+
+def uc8_lut() -> np.ndarray:
+    p = lib().rsb_uc8_lut()
+    return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint16)), shape=(65536,)).copy()

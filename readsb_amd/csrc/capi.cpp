@@ -1,0 +1,390 @@
+// capi.cpp -- the C ABI of include/readsb_amd.h over the HIP kernels and the host replay.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ctx.hpp"
+
+using namespace rsb;
+
+namespace {
+
+bool fail(rsb_ctx *c, const char *what, hipError_t e) {
+    char buf[256];
+    std::snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    if (c) c->err = buf;
+    return false;
+}
+
+#define HIP_TRY(ctx, call)                      \
+    do {                                        \
+        hipError_t e_ = (call);                 \
+        if (e_ != hipSuccess) {                 \
+            fail(ctx, #call, e_);               \
+            return RSB_ENODEV;                  \
+        }                                       \
+    } while (0)
+
+template <typename T>
+int upload(rsb_ctx *c, T **dst, const T *src, size_t count) {
+    HIP_TRY(c, hipMalloc((void **)dst, count * sizeof(T)));
+    HIP_TRY(c, hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return RSB_OK;
+}
+
+int setup_device(rsb_ctx *c) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        c->err = "no HIP device available (this library has no CPU fallback)";
+        return RSB_ENODEV;
+    }
+    if (c->cfg.device < 0 || c->cfg.device >= ndev) {
+        c->err = "rsb_config.device out of range";
+        return RSB_EINVAL;
+    }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+
+    int rc;
+    if ((rc = upload(c, &c->d_lut, uc8_magnitude_lut(), 65536)) != RSB_OK) return rc;
+    if ((rc = upload(c, &c->d_crc_bytes, CrcTables::byte_table(), 256)) != RSB_OK) return rc;
+    for (int w = 0; w < 2; ++w) {
+        DevSyndromeTable t = c->replay.crc().device_table(w == 0 ? 56 : 112);
+        c->syn_mask[w] = t.mask;
+        if (c->replay.crc().table(w == 0 ? 56 : 112).empty()) continue;  // --no-fix: no table (crc.c:358-360)
+        if ((rc = upload(c, &c->d_syn_keys[w], t.keys.data(), t.keys.size())) != RSB_OK) return rc;
+        if ((rc = upload(c, &c->d_syn_vals[w], t.vals.data(), t.vals.size())) != RSB_OK) return rc;
+    }
+
+    const uint64_t nmax = c->cfg.max_batch_samples;
+    const uint32_t div = c->cfg.queue_div ? c->cfg.queue_div : 32;
+    uint64_t cap = nmax / div;
+    if (cap < 4096) cap = 4096;
+    if (cap > 0x7fffffffull) cap = 0x7fffffffull;
+    c->key_cap = (uint32_t)cap;
+    c->surv_cap = (uint32_t)cap;
+    c->ac_cap = (uint32_t)cap;
+    c->nblocks_cap = (nmax + kBlock - 1) / kBlock + 1;
+    HIP_TRY(c, hipMalloc((void **)&c->d_keys, (size_t)c->key_cap * sizeof(KeyRec)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_surv_g, (size_t)c->surv_cap * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_surv, (size_t)c->surv_cap * sizeof(Survivor)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_ac, (size_t)c->ac_cap * sizeof(AcCand)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_bitmap, (1u << 24) / 8));
+    HIP_TRY(c, hipMalloc((void **)&c->d_counters, kCntCount * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_block_sums, c->nblocks_cap * 2 * sizeof(uint64_t)));
+    HIP_TRY(c, hipMalloc(&c->d_carry, kTrailing * 4));
+    for (hipEvent_t &ev : c->ev) HIP_TRY(c, hipEventCreate(&ev));
+    return RSB_OK;
+}
+
+int reset_device(rsb_ctx *c) {
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipMemset(c->d_bitmap, 0, (1u << 24) / 8));
+    // icaoFilterTest(0) is true on an empty slot (icao_filter.c:101-107): address 0 is always a "member"
+    const uint32_t one = 1;
+    HIP_TRY(c, hipMemcpy(c->d_bitmap, &one, sizeof(one), hipMemcpyHostToDevice));
+    return RSB_OK;
+}
+
+const CrcTables &tables_for(int fix_bits) {
+    static const CrcTables t0(0), t1(1), t2(2);
+    return fix_bits <= 0 ? t0 : (fix_bits == 1 ? t1 : t2);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rsb_version(void) { return "readsb_amd 0.1 (gfx950)"; }
+
+int rsb_create(const rsb_config *cfg, rsb_ctx **out) {
+    if (!cfg || !out) return RSB_EINVAL;
+    *out = nullptr;
+    if (cfg->input_format < RSB_UC8 || cfg->input_format > RSB_SC16Q11) {
+        // convert.c:460-464
+        std::fprintf(stderr, "no suitable converter for format=%d dc=%d\n", cfg->input_format, cfg->dc_filter);
+        return RSB_EINVAL;
+    }
+    if (cfg->dc_filter) {
+        std::fprintf(stderr, "readsb_amd: --dcfilter is not available on the GPU path yet\n");
+        return RSB_EINVAL;
+    }
+    if (cfg->fix_bits < 0 || cfg->max_batch_samples == 0 || cfg->max_batch_samples > 0xfffff000ull) return RSB_EINVAL;
+    if (cfg->mode_ac && cfg->input_format != RSB_UC8) {
+        std::fprintf(stderr, "readsb_amd: --modeac needs the integer block statistics of the UC8 converter\n");
+        return RSB_EINVAL;
+    }
+    rsb_ctx *c = new (std::nothrow) rsb_ctx(*cfg);
+    if (!c) return RSB_ENOMEM;
+    int rc = setup_device(c);
+    if (rc == RSB_OK) rc = reset_device(c);
+    if (rc != RSB_OK) {
+        std::fprintf(stderr, "readsb_amd: %s\n", c->err.c_str());
+        rsb_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return RSB_OK;
+}
+
+void rsb_destroy(rsb_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1],
+                    c->d_keys, c->d_surv_g, c->d_surv, c->d_ac, c->d_bitmap, c->d_counters, c->d_block_sums, c->d_carry,
+                    c->d_stage, c->d_mag, c->d_sums};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    delete c;
+}
+
+int rsb_reset(rsb_ctx *c) {
+    if (!c) return RSB_EINVAL;
+    c->replay.reset();
+    c->stream_pos = 0;
+    c->carry_valid = 0;
+    c->pending = false;
+    c->finished = false;
+    std::memset(&c->timing, 0, sizeof(c->timing));
+    return reset_device(c);
+}
+
+int rsb_filter_add(rsb_ctx *c, uint32_t addr) {
+    if (!c) return RSB_EINVAL;
+    addr &= 0xffffffu;
+    c->replay.filter().add(addr);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    uint32_t word = 0;
+    HIP_TRY(c, hipMemcpy(&word, c->d_bitmap + (addr >> 5), 4, hipMemcpyDeviceToHost));
+    word |= 1u << (addr & 31);
+    HIP_TRY(c, hipMemcpy(c->d_bitmap + (addr >> 5), &word, 4, hipMemcpyHostToDevice));
+    return RSB_OK;
+}
+
+int rsb_filter_expire(rsb_ctx *c) {
+    if (!c) return RSB_EINVAL;
+    // the device bitmap stays a superset (it only ever grows), which is all the prune needs
+    c->replay.filter().expire();
+    return RSB_OK;
+}
+
+int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) {
+    if (!c || (!iq_dev && nsamples)) return RSB_EINVAL;
+    if (c->pending) {
+        c->err = "rsb_submit: previous batch not collected";
+        return RSB_ESTATE;
+    }
+    if (c->finished || c->stream_pos % kBlock != 0) {
+        c->err = "rsb_submit: stream position is not a multiple of 131072 (only the last batch may be partial)";
+        return RSB_ESTATE;
+    }
+    if (nsamples > c->cfg.max_batch_samples) {
+        c->err = "rsb_submit: nsamples exceeds rsb_config.max_batch_samples";
+        return RSB_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const unsigned bps = (c->cfg.input_format == RSB_UC8) ? 2 : 4;
+
+    BatchArgs a = c->batch_args(iq_dev, nsamples, c->cfg.input_format);
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCntCount * sizeof(uint32_t), s));
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    HIP_TRY(c, launch_scan(a, s));
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    HIP_TRY(c, launch_prune_finalize(a, s));
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    if (c->cfg.mode_ac && nsamples) {
+        const size_t nblk = (nsamples + kBlock - 1) / kBlock;
+        HIP_TRY(c, hipMemsetAsync(c->d_block_sums, 0, nblk * 2 * sizeof(uint64_t), s));
+        HIP_TRY(c, launch_modeac(a, s));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    if (nsamples % kBlock == 0 && nsamples) {
+        // the next batch's 326-sample overlap (sdr_ifile.c:199-201)
+        HIP_TRY(c, hipMemcpyAsync(c->d_carry, (const char *)iq_dev + (nsamples - kTrailing) * bps, (size_t)kTrailing * bps,
+                                  hipMemcpyDeviceToDevice, s));
+    }
+    c->pending = true;
+    c->pending_n = nsamples;
+    c->pending_stream = s;
+    return RSB_OK;
+}
+
+int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
+    if (!c || (!out && cap)) return RSB_EINVAL;
+    if (n_out) *n_out = 0;
+    if (!c->pending) {
+        c->err = "rsb_collect: nothing submitted";
+        return RSB_ESTATE;
+    }
+    c->pending = false;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t s = c->pending_stream;
+    uint32_t cnt[kCntCount];
+    HIP_TRY(c, hipMemcpyAsync(cnt, c->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (cnt[kCntKeys] > c->key_cap || cnt[kCntSurvivors] > c->surv_cap || cnt[kCntAc] > c->ac_cap) {
+        char buf[200];
+        std::snprintf(buf, sizeof(buf), "device queue overflow: keys %u/%u survivors %u/%u modeac %u/%u", cnt[kCntKeys], c->key_cap,
+                      cnt[kCntSurvivors], c->surv_cap, cnt[kCntAc], c->ac_cap);
+        c->err = buf;
+        c->finished = true;
+        return RSB_EOVERFLOW;
+    }
+    c->h_surv.resize(cnt[kCntSurvivors]);
+    c->h_ac.resize(cnt[kCntAc]);
+    if (cnt[kCntSurvivors])
+        HIP_TRY(c, hipMemcpyAsync(c->h_surv.data(), c->d_surv, cnt[kCntSurvivors] * sizeof(Survivor), hipMemcpyDeviceToHost, s));
+    if (cnt[kCntAc]) HIP_TRY(c, hipMemcpyAsync(c->h_ac.data(), c->d_ac, cnt[kCntAc] * sizeof(AcCand), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+
+    (void)hipEventElapsedTime(&c->timing.scan_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&c->timing.prune_ms, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&c->timing.modeac_ms, c->ev[2], c->ev[3]);
+    (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[3]);
+
+    const auto t0 = std::chrono::steady_clock::now();
+    c->msgs.clear();
+    c->replay.run_batch(c->stream_pos, c->h_surv, c->h_ac, c->msgs);
+    c->timing.replay_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+    rsb_stats &st = c->replay.stats();
+    st.samples_processed += c->pending_n;
+    st.gated_offsets += cnt[kCntGated];
+    st.live_candidates += cnt[kCntKeys];
+    st.survivors += cnt[kCntSurvivors];
+    st.modeac_candidates += cnt[kCntAc];
+
+    c->stream_pos += c->pending_n;
+    if (c->pending_n % kBlock != 0) c->finished = true;
+    if (c->pending_n % kBlock == 0 && c->pending_n) c->carry_valid = 1;
+
+    const size_t n = c->msgs.size();
+    if (n_out) *n_out = n;
+    const size_t ncopy = n < cap ? n : cap;
+    if (ncopy) std::memcpy(out, c->msgs.data(), ncopy * sizeof(rsb_message));
+    if (n > cap) {
+        c->err = "rsb_collect: output buffer too small";
+        return RSB_EOVERFLOW;
+    }
+    return RSB_OK;
+}
+
+int rsb_process(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream, rsb_message *out, size_t cap, size_t *n_out) {
+    const int rc = rsb_submit(c, iq_dev, nsamples, stream);
+    if (rc != RSB_OK) return rc;
+    return rsb_collect(c, out, cap, n_out);
+}
+
+int rsb_process_host(rsb_ctx *c, const void *iq_host, uint64_t nsamples, rsb_message *out, size_t cap, size_t *n_out) {
+    if (!c || (!iq_host && nsamples)) return RSB_EINVAL;
+    const unsigned bps = (c->cfg.input_format == RSB_UC8) ? 2 : 4;
+    const size_t bytes = (size_t)nsamples * bps;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (bytes > c->stage_bytes) {
+        if (c->d_stage) (void)hipFree(c->d_stage);
+        c->d_stage = nullptr;
+        c->stage_bytes = 0;
+        HIP_TRY(c, hipMalloc(&c->d_stage, bytes));
+        c->stage_bytes = bytes;
+    }
+    if (bytes) HIP_TRY(c, hipMemcpy(c->d_stage, iq_host, bytes, hipMemcpyHostToDevice));
+    return rsb_process(c, c->d_stage ? c->d_stage : (const void *)c->d_carry, nsamples, nullptr, out, cap, n_out);
+}
+
+int rsb_get_stats(const rsb_ctx *c, rsb_stats *st) {
+    if (!c || !st) return RSB_EINVAL;
+    *st = const_cast<rsb_ctx *>(c)->replay.stats();
+    return RSB_OK;
+}
+
+int rsb_get_timing(const rsb_ctx *c, rsb_timing *t) {
+    if (!c || !t) return RSB_EINVAL;
+    *t = c->timing;
+    return RSB_OK;
+}
+
+const char *rsb_last_error(const rsb_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int rsb_convert_device(rsb_ctx *c, const void *iq_dev, void *mag_dev, uint64_t nsamples, void *stream, double *mean_level,
+                       double *mean_power) {
+    if (!c || !iq_dev || !mag_dev) return RSB_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const bool want = mean_level || mean_power;
+    if (want && !c->d_sums) HIP_TRY(c, hipMalloc((void **)&c->d_sums, 2 * sizeof(uint64_t)));
+    if (want) HIP_TRY(c, hipMemsetAsync(c->d_sums, 0, 2 * sizeof(uint64_t), s));
+    HIP_TRY(c, launch_convert(c->cfg.input_format, iq_dev, (uint16_t *)mag_dev, nsamples, c->d_lut, want ? c->d_sums : nullptr, s));
+    if (want) {
+        uint64_t sums[2];
+        HIP_TRY(c, hipMemcpyAsync(sums, c->d_sums, sizeof(sums), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        // convert.c:104-110 (integer converters; the float converters' sequential float32 sums are not reproduced here)
+        if (mean_level) *mean_level = sums[0] / 65536.0 / (unsigned)nsamples;
+        if (mean_power) *mean_power = sums[1] / 65535.0 / 65535.0 / (unsigned)nsamples;
+    }
+    return RSB_OK;
+}
+
+uint32_t rsb_checksum(const uint8_t *msg, int bits) {
+    if (!msg || (bits != 56 && bits != 112)) return 0xffffffffu;  // crc.c:72-73 asserts instead
+    return CrcTables::checksum(msg, bits);
+}
+
+int rsb_diagnose(const rsb_ctx *c, uint32_t syndrome, int bits, int bitpos[2]) {
+    if (!c || (bits != 56 && bits != 112)) return -1;
+    const SyndromeEntry *e = c->replay.crc().diagnose(syndrome, bits);
+    if (!e) return -1;
+    if (bitpos) {
+        bitpos[0] = e->errors > 0 ? e->bit[0] : -1;
+        bitpos[1] = e->errors > 1 ? e->bit[1] : -1;
+    }
+    return e->errors;
+}
+
+static_assert(sizeof(rsb_candidate) == sizeof(Survivor) && sizeof(rsb_ac_candidate) == sizeof(AcCand), "public record layouts");
+
+int rsb_crc_table_size(int fix_bits, int bits) {
+    if (bits != 56 && bits != 112) return -1;
+    return (int)tables_for(fix_bits).table(bits).size();
+}
+
+int rsb_crc_table_entry(int fix_bits, int bits, int idx, uint32_t *syndrome, int *errors, int bitpos[2]) {
+    if (bits != 56 && bits != 112) return RSB_EINVAL;
+    const std::vector<SyndromeEntry> &t = tables_for(fix_bits).table(bits);
+    if (idx < 0 || (size_t)idx >= t.size()) return RSB_EINVAL;
+    if (syndrome) *syndrome = t[idx].syndrome;
+    if (errors) *errors = t[idx].errors;
+    if (bitpos) {
+        bitpos[0] = t[idx].bit[0];
+        bitpos[1] = t[idx].bit[1];
+    }
+    return RSB_OK;
+}
+
+const uint16_t *rsb_uc8_lut(void) { return uc8_magnitude_lut(); }
+
+int rsb_host_replay(int fix_bits, uint64_t g0, const rsb_candidate *cands, size_t ncands, const rsb_ac_candidate *ac, size_t nac,
+                    rsb_message *out, size_t cap, size_t *n_out) {
+    if ((!cands && ncands) || (!ac && nac) || (!out && cap) || g0 % kBlock) return RSB_EINVAL;
+    Replayer r(fix_bits);
+    std::vector<Survivor> s(ncands);
+    std::vector<AcCand> a(nac);
+    if (ncands) std::memcpy(s.data(), cands, ncands * sizeof(Survivor));
+    if (nac) std::memcpy(a.data(), ac, nac * sizeof(AcCand));
+    std::vector<rsb_message> msgs;
+    r.run_batch(g0, s, a, msgs);
+    if (n_out) *n_out = msgs.size();
+    const size_t ncopy = msgs.size() < cap ? msgs.size() : cap;
+    if (ncopy) std::memcpy(out, msgs.data(), ncopy * sizeof(rsb_message));
+    return msgs.size() > cap ? RSB_EOVERFLOW : RSB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// ctx.hpp -- the context behind the opaque rsb_ctx of include/readsb_amd.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "modes_host.hpp"
+
+struct rsb_ctx {
+    explicit rsb_ctx(const rsb_config &c) : cfg(c), replay(c.fix_bits) {
+        std::memset(&timing, 0, sizeof(timing));
+        for (hipEvent_t &e : ev) e = nullptr;
+    }
+
+    rsb_config cfg;
+    rsb::Replayer replay;
+
+    // read-only device tables
+    uint16_t *d_lut = nullptr;
+    uint32_t *d_crc_bytes = nullptr;
+    uint32_t *d_syn_keys[2] = {nullptr, nullptr};
+    uint32_t *d_syn_vals[2] = {nullptr, nullptr};
+    uint32_t syn_mask[2] = {0, 0};
+
+    // device work buffers
+    rsb::KeyRec *d_keys = nullptr;
+    uint32_t *d_surv_g = nullptr;
+    rsb::Survivor *d_surv = nullptr;
+    rsb::AcCand *d_ac = nullptr;
+    uint32_t key_cap = 0, surv_cap = 0, ac_cap = 0;
+    uint32_t *d_bitmap = nullptr;
+    uint32_t *d_counters = nullptr;
+    uint64_t *d_block_sums = nullptr;
+    size_t nblocks_cap = 0;
+    void *d_carry = nullptr;
+    void *d_stage = nullptr;
+    size_t stage_bytes = 0;
+    uint16_t *d_mag = nullptr;  // drop-in block path
+    uint64_t *d_sums = nullptr;
+
+    // stream state
+    uint64_t stream_pos = 0;
+    int carry_valid = 0;
+    bool pending = false, finished = false;
+    uint64_t pending_n = 0;
+    hipStream_t pending_stream = nullptr;
+
+    hipEvent_t ev[4];
+    rsb_timing timing;
+    std::string err;
+    std::vector<rsb::Survivor> h_surv;
+    std::vector<rsb::AcCand> h_ac;
+    std::vector<rsb_message> msgs;
+
+    rsb::BatchArgs batch_args(const void *iq, uint64_t n, int fmt) const {
+        rsb::BatchArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.iq = iq;
+        a.carry = d_carry;
+        a.carry_valid = carry_valid;
+        a.fmt = fmt;
+        a.n = n;
+        a.tab.uc8_lut = d_lut;
+        a.tab.crc_bytes = d_crc_bytes;
+        for (int w = 0; w < 2; ++w) {
+            a.tab.syn_keys[w] = d_syn_keys[w];
+            a.tab.syn_vals[w] = d_syn_vals[w];
+            a.tab.syn_mask[w] = syn_mask[w];
+        }
+        a.tab.nfix = cfg.fix_bits;
+        a.keys = d_keys;
+        a.key_cap = key_cap;
+        a.surv_g = d_surv_g;
+        a.survivors = d_surv;
+        a.surv_cap = surv_cap;
+        a.ac = d_ac;
+        a.ac_cap = ac_cap;
+        a.adder_bitmap = d_bitmap;
+        a.counters = d_counters;
+        a.block_sums = d_block_sums;
+        a.emit_dead = 0;
+        a.keep_all = 0;
+        return a;
+    }
+};

@@ -1,0 +1,27 @@
+"""Seeded scenarios shared by the CPU and GPU tests (sizes the oracle finishes in well under a second)."""
+from readsb_amd.synth import Scenario
+
+B = 131072
+
+SCENARIOS = {
+    # BASELINE config 1 at reduced size: DF11/DF17 traffic, mixed SNR, every 7th frame with a 1-bit error
+    "cfg1_df11_df17": (Scenario(2_400_000, seed=1, mix={"df17": 0.7, "df11": 0.3}, collide_every=0, df11_iid_every=0),
+                       dict(nfix=1, modeac=False)),
+    # all DFs, near-collisions, DF11 with interrogator ids, 1-bit errors
+    "mixed_fix1": (Scenario(2_000_000, seed=7), dict(nfix=1, modeac=False)),
+    # BASELINE config 5 at reduced size: dense, low SNR, 2-bit errors, Mode A/C, --aggressive
+    "dense_fix2_ac": (Scenario(3_000_000, seed=2, frames_per_sec=4000, err1_every=7, err2_every=10, modeac_per_sec=300,
+                               amp_lo=0.04, amp_hi=0.54), dict(nfix=2, modeac=True)),
+    "dense_fix1_ac": (Scenario(3_000_000, seed=2, frames_per_sec=4000, err1_every=7, err2_every=10, modeac_per_sec=300,
+                               amp_lo=0.04, amp_hi=0.54), dict(nfix=1, modeac=True)),
+    "nofix": (Scenario(1_000_000, seed=4), dict(nfix=0, modeac=False)),
+    "noise_ac": (Scenario(4_000_000, seed=3, frames_per_sec=0, noise_lsb=3.0), dict(nfix=1, modeac=True)),
+    # ragged sizes: shorter than one block, shorter than the overlap, exact multiples of a block
+    "tiny_200": (Scenario(200, seed=8, frames_per_sec=0), dict(nfix=1, modeac=True)),
+    "short_5000": (Scenario(5000, seed=9, frames_per_sec=20000), dict(nfix=1, modeac=True)),
+    "exact_2_blocks": (Scenario(2 * B, seed=10, frames_per_sec=3000, modeac_per_sec=300), dict(nfix=1, modeac=True)),
+    "block_plus_1": (Scenario(B + 1, seed=12, frames_per_sec=3000), dict(nfix=1, modeac=False)),
+    # BASELINE config 3 (no-DC part): bladeRF / Pluto formats
+    "sc16": (Scenario(1_000_000, seed=5, fmt="SC16"), dict(nfix=1, modeac=False)),
+    "sc16q11": (Scenario(1_000_000, seed=5, fmt="SC16Q11"), dict(nfix=1, modeac=False)),
+}
