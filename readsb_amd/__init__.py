@@ -131,8 +131,10 @@ class Channel:
     def submit(self, dev_ptr: int, nsamples: int, stream: int = 0):
         self._check(self.l.rsb_submit(self.h, dev_ptr, nsamples, stream), "rsb_submit")
 
-    def collect(self, cap: int = 1 << 16) -> np.ndarray:
-        out = np.zeros(cap, dtype=MSG_DTYPE)
+    def collect(self, cap: int = 1 << 16, out: np.ndarray | None = None) -> np.ndarray:
+        if out is None:
+            out = np.zeros(cap, dtype=MSG_DTYPE)
+        cap = out.size
         n = _SZ()
         rc = self.l.rsb_collect(self.h, out.ctypes.data, cap, C.byref(n))
         if rc == -4 and n.value > cap:
