@@ -171,7 +171,7 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": "configs[1]: 1 Gsample synthetic UC8 recording, mixed SNR, demodulate2400 + 1-bit CRC correction",
                        "samples_per_gpu": n, "segment_samples": seg_n, "format": "UC8", "fix_bits": 1,
-                       "channels": world, "messages_per_step": nmsgs, "survivors_per_step": st["survivors"] // max(1, args.steps + args.warmup),
+                       "channels": world, "messages_per_step": nmsgs, "survivors_per_step": st["survivors"],
                        "full_size_check": parity},
             "roofline": {"bound": "hbm", "kernel": "k_scan<UC8>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -25,3 +25,39 @@ SCENARIOS = {
     "sc16": (Scenario(1_000_000, seed=5, fmt="SC16"), dict(nfix=1, modeac=False)),
     "sc16q11": (Scenario(1_000_000, seed=5, fmt="SC16Q11"), dict(nfix=1, modeac=False)),
 }
+
+# --dcfilter scenarios (float IIR path; CPU oracle only for now)
+SCENARIOS.update({
+    "uc8_dc": (Scenario(600_000, seed=6, dc_offset=0.03), dict(nfix=1, modeac=False, dc_filter=True)),
+    "sc16_dc": (Scenario(600_000, seed=5, fmt="SC16", dc_offset=0.02), dict(nfix=1, modeac=False, dc_filter=True)),
+    "sc16q11_dc_ac": (Scenario(600_000, seed=5, fmt="SC16Q11", dc_offset=0.02, modeac_per_sec=300), dict(nfix=1, modeac=True, dc_filter=True)),
+    "sc16_ac": (Scenario(600_000, seed=13, fmt="SC16", modeac_per_sec=300), dict(nfix=1, modeac=True)),
+})
+
+# scenarios the GPU path supports today
+GPU_SCENARIOS = [k for k, (sc, kw) in SCENARIOS.items() if not kw.get("dc_filter") and not (kw["modeac"] and sc.fmt != "UC8")]
+
+# converter known-answer cases: name -> (format, dc_filter, samples, samples per converter call)
+CONVERT_CASES = {
+    "uc8": ("UC8", False, 200_000, 131072),
+    "uc8_dc": ("UC8", True, 100_000, 30_000),
+    "sc16": ("SC16", False, 100_000, 30_000),
+    "sc16_dc": ("SC16", True, 100_000, 30_000),
+    "sc16q11": ("SC16Q11", False, 100_000, 30_000),
+    "sc16q11_dc": ("SC16Q11", True, 100_000, 30_000),
+}
+
+
+def convert_input(fmt, n):
+    """Uniform random IQ over the full code range plus the corner values (convert_benchmark.c:63-80 style)."""
+    import numpy as np
+
+    rng = np.random.Generator(np.random.PCG64(99))
+    if fmt == "UC8":
+        iq = rng.integers(0, 256, size=(n, 2), dtype=np.uint8)
+        iq[:6] = [[127, 127], [128, 128], [130, 127], [200, 100], [255, 128], [0, 0]]
+        return iq
+    lim = 32768 if fmt == "SC16" else 2048
+    iq = rng.integers(-lim, lim, size=(n, 2), dtype=np.int64).astype("<i2")
+    iq[:6] = [[1000, -2000], [lim - 1, 0], [-lim, -lim], [123, 456], [0, 0], [-1, 1]]
+    return iq

@@ -6,16 +6,19 @@ import readsb_amd
 from oracle.oracle import Oracle, REC_DTYPE, first_mismatch
 from readsb_amd.synth import generate
 
-from scenarios import SCENARIOS
+from scenarios import GPU_SCENARIOS, SCENARIOS
+from test_oracle import load_demod
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", list(SCENARIOS))
-def test_stream_matches_oracle(name, built):
+@pytest.mark.parametrize("name", GPU_SCENARIOS)
+def test_stream_matches_oracle_and_golden(name, built):
     sc, kw = SCENARIOS[name]
     iq = generate(sc)
     want, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
+    gold, _, _ = load_demod(name)  # what the unmodified reference produced for this input
+    assert first_mismatch(gold, want) is None
     ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=1 << 23)
     got = ch.process_host(iq)
     assert first_mismatch(want, got.view(REC_DTYPE)) is None
