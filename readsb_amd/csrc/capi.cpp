@@ -66,12 +66,19 @@ int setup_device(rsb_ctx *c) {
     uint64_t cap = nmax / div;
     if (cap < 4096) cap = 4096;
     if (cap > 0x7fffffffull) cap = 0x7fffffffull;
-    c->key_cap = (uint32_t)cap;
-    c->surv_cap = (uint32_t)cap;
-    c->ac_cap = (uint32_t)cap;
+    c->item_cap = (uint32_t)cap;
+    c->surv_cap = (uint32_t)(cap / 4 < 4096 ? 4096 : cap / 4);
+    c->ac_cap = (uint32_t)(cap / 4 < 4096 ? 4096 : cap / 4);
     c->nblocks_cap = (nmax + kBlock - 1) / kBlock + 1;
-    HIP_TRY(c, hipMalloc((void **)&c->d_keys, (size_t)c->key_cap * sizeof(KeyRec)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_surv_g, (size_t)c->surv_cap * sizeof(uint32_t)));
+    c->scan_grid = scan_grid_size(c->cfg.device);
+    HIP_TRY(c, hipMalloc((void **)&c->d_items, (size_t)c->item_cap * sizeof(ItemRec)));
+    for (int w = 0; w < 2; ++w) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_skeys[w], (size_t)c->item_cap * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_sinfo[w], (size_t)c->item_cap * sizeof(uint32_t)));
+    }
+    c->sort_temp_bytes = sort_temp_bytes(c->item_cap);
+    HIP_TRY(c, hipMalloc(&c->d_sort_temp, c->sort_temp_bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->d_surv_g, (size_t)c->item_cap * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_surv, (size_t)c->surv_cap * sizeof(Survivor)));
     HIP_TRY(c, hipMalloc((void **)&c->d_ac, (size_t)c->ac_cap * sizeof(AcCand)));
     HIP_TRY(c, hipMalloc((void **)&c->d_bitmap, (1u << 24) / 8));
@@ -136,7 +143,7 @@ void rsb_destroy(rsb_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1],
-                    c->d_keys, c->d_surv_g, c->d_surv, c->d_ac, c->d_bitmap, c->d_counters, c->d_block_sums, c->d_carry,
+                    c->d_items, c->d_skeys[0], c->d_skeys[1], c->d_sinfo[0], c->d_sinfo[1], c->d_sort_temp, c->d_surv_g, c->d_surv, c->d_ac, c->d_bitmap, c->d_counters, c->d_block_sums, c->d_carry,
                     c->d_stage, c->d_mag, c->d_sums};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -191,14 +198,12 @@ int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) 
     }
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const unsigned bps = (c->cfg.input_format == RSB_UC8) ? 2 : 4;
-
     BatchArgs a = c->batch_args(iq_dev, nsamples, c->cfg.input_format);
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCntCount * sizeof(uint32_t), s));
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    HIP_TRY(c, launch_scan(a, s));
+    HIP_TRY(c, launch_scan(a, c->scan_grid, s));
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
-    HIP_TRY(c, launch_prune_finalize(a, s));
+    HIP_TRY(c, launch_prune(a, s));
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
     if (c->cfg.mode_ac && nsamples) {
         const size_t nblk = (nsamples + kBlock - 1) / kBlock;
@@ -206,14 +211,10 @@ int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) 
         HIP_TRY(c, launch_modeac(a, s));
     }
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
-    if (nsamples % kBlock == 0 && nsamples) {
-        // the next batch's 326-sample overlap (sdr_ifile.c:199-201)
-        HIP_TRY(c, hipMemcpyAsync(c->d_carry, (const char *)iq_dev + (nsamples - kTrailing) * bps, (size_t)kTrailing * bps,
-                                  hipMemcpyDeviceToDevice, s));
-    }
     c->pending = true;
     c->pending_n = nsamples;
     c->pending_stream = s;
+    c->pending_args = a;
     return RSB_OK;
 }
 
@@ -230,25 +231,49 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     uint32_t cnt[kCntCount];
     HIP_TRY(c, hipMemcpyAsync(cnt, c->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    if (cnt[kCntKeys] > c->key_cap || cnt[kCntSurvivors] > c->surv_cap || cnt[kCntAc] > c->ac_cap) {
+    if (cnt[kCntItems] > c->item_cap || cnt[kCntAc] > c->ac_cap) {
         char buf[200];
-        std::snprintf(buf, sizeof(buf), "device queue overflow: keys %u/%u survivors %u/%u modeac %u/%u", cnt[kCntKeys], c->key_cap,
-                      cnt[kCntSurvivors], c->surv_cap, cnt[kCntAc], c->ac_cap);
+        std::snprintf(buf, sizeof(buf), "device queue overflow: items %u/%u modeac %u/%u (lower rsb_config.queue_div)", cnt[kCntItems],
+                      c->item_cap, cnt[kCntAc], c->ac_cap);
         c->err = buf;
         c->finished = true;
         return RSB_EOVERFLOW;
     }
-    c->h_surv.resize(cnt[kCntSurvivors]);
+    // kept items -> sorted -> distinct offsets -> full candidate records
+    HIP_TRY(c, hipEventRecord(c->ev[4], s));
+    HIP_TRY(c, launch_sort_unique_finalize(c->pending_args, cnt[kCntSurvItems], c->d_sort_temp, c->sort_temp_bytes, &c->sorted_buf, s));
+    HIP_TRY(c, hipEventRecord(c->ev[5], s));
+    if (c->pending_n % kBlock == 0 && c->pending_n) {
+        // the next batch's 326-sample overlap (sdr_ifile.c:199-201); only now, the finalize kernel still read the old one
+        const unsigned bps = (c->cfg.input_format == RSB_UC8) ? 2 : 4;
+        HIP_TRY(c, hipMemcpyAsync(c->d_carry, (const char *)c->pending_args.iq + (c->pending_n - kTrailing) * bps, (size_t)kTrailing * bps,
+                                  hipMemcpyDeviceToDevice, s));
+    }
+    uint32_t nsurv = 0;
+    HIP_TRY(c, hipMemcpyAsync(&nsurv, c->d_counters + kCntSurvivors, sizeof(nsurv), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (nsurv > c->surv_cap) {
+        char buf[200];
+        std::snprintf(buf, sizeof(buf), "device queue overflow: surviving offsets %u/%u (lower rsb_config.queue_div)", nsurv, c->surv_cap);
+        c->err = buf;
+        c->finished = true;
+        return RSB_EOVERFLOW;
+    }
+    cnt[kCntSurvivors] = nsurv;
+    c->h_surv.resize(nsurv);
     c->h_ac.resize(cnt[kCntAc]);
-    if (cnt[kCntSurvivors])
-        HIP_TRY(c, hipMemcpyAsync(c->h_surv.data(), c->d_surv, cnt[kCntSurvivors] * sizeof(Survivor), hipMemcpyDeviceToHost, s));
+    if (nsurv) HIP_TRY(c, hipMemcpyAsync(c->h_surv.data(), c->d_surv, nsurv * sizeof(Survivor), hipMemcpyDeviceToHost, s));
     if (cnt[kCntAc]) HIP_TRY(c, hipMemcpyAsync(c->h_ac.data(), c->d_ac, cnt[kCntAc] * sizeof(AcCand), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
 
+    float finalize_ms = 0;
     (void)hipEventElapsedTime(&c->timing.scan_ms, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&c->timing.prune_ms, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&c->timing.modeac_ms, c->ev[2], c->ev[3]);
     (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[3]);
+    (void)hipEventElapsedTime(&finalize_ms, c->ev[4], c->ev[5]);
+    c->timing.prune_ms += finalize_ms;
+    c->timing.total_ms += finalize_ms;
 
     const auto t0 = std::chrono::steady_clock::now();
     c->msgs.clear();
@@ -258,7 +283,7 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     rsb_stats &st = c->replay.stats();
     st.samples_processed += c->pending_n;
     st.gated_offsets += cnt[kCntGated];
-    st.live_candidates += cnt[kCntKeys];
+    st.live_candidates += cnt[kCntItems];
     st.survivors += cnt[kCntSurvivors];
     st.modeac_candidates += cnt[kCntAc];
 

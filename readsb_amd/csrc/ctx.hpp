@@ -27,11 +27,17 @@ struct rsb_ctx {
     uint32_t syn_mask[2] = {0, 0};
 
     // device work buffers
-    rsb::KeyRec *d_keys = nullptr;
+    rsb::ItemRec *d_items = nullptr;
+    uint64_t *d_skeys[2] = {nullptr, nullptr};
+    uint32_t *d_sinfo[2] = {nullptr, nullptr};
     uint32_t *d_surv_g = nullptr;
     rsb::Survivor *d_surv = nullptr;
     rsb::AcCand *d_ac = nullptr;
-    uint32_t key_cap = 0, surv_cap = 0, ac_cap = 0;
+    void *d_sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+    uint32_t item_cap = 0, surv_cap = 0, ac_cap = 0;
+    int scan_grid = 512;
+    int sorted_buf = 0;
     uint32_t *d_bitmap = nullptr;
     uint32_t *d_counters = nullptr;
     uint64_t *d_block_sums = nullptr;
@@ -48,8 +54,9 @@ struct rsb_ctx {
     bool pending = false, finished = false;
     uint64_t pending_n = 0;
     hipStream_t pending_stream = nullptr;
+    rsb::BatchArgs pending_args;
 
-    hipEvent_t ev[4];
+    hipEvent_t ev[6];
     rsb_timing timing;
     std::string err;
     std::vector<rsb::Survivor> h_surv;
@@ -72,8 +79,13 @@ struct rsb_ctx {
             a.tab.syn_mask[w] = syn_mask[w];
         }
         a.tab.nfix = cfg.fix_bits;
-        a.keys = d_keys;
-        a.key_cap = key_cap;
+        a.iq_aligned = ((uintptr_t)iq % 16 == 0) ? 1 : 0;
+        a.items = d_items;
+        a.item_cap = item_cap;
+        for (int w = 0; w < 2; ++w) {
+            a.skeys[w] = d_skeys[w];
+            a.sinfo[w] = d_sinfo[w];
+        }
         a.surv_g = d_surv_g;
         a.survivors = d_surv;
         a.surv_cap = surv_cap;

@@ -1,15 +1,17 @@
 // kernels.hip -- gfx950 kernels of the receive path.
 //
-//   k_scan      convert.c (IQ -> magnitude, in registers/LDS only) + demod_2400.c:109-172 (preamble
-//               gate, one thread per scan offset) + :179-286 (five trial phases, bit slicing) +
-//               crc.c:67-82 / :383-406 (syndrome, error-table lookup) + the filter-independent half
-//               of mode_s.c:311-409.  Emits one 24-byte key record per gated offset that can still
-//               score >= 0 under some filter state, and marks every address the filter could ever
-//               learn (mode_s.c:717-726) in a 2^24-bit set.
-//   k_prune     drops key records whose every live phase needs a filter member that is not in that
-//               superset (safe: such an offset is rejected by demod_2400.c:304-310 whatever happened
-//               before it, and a rejected offset neither skips nor adds).
-//   k_finalize  re-slices the few survivors into full records (5 x 14 message bytes + the signal
+//   k_scan      persistent workgroups; per 8192-offset tile: convert.c (IQ -> magnitude through a
+//               folded 32 KB LUT in LDS, magnitudes live in LDS only) -> demod_2400.c:109-155 as
+//               bit-parallel wavefront ballots (edge patterns of 64 lanes x 8 offsets per scalar op)
+//               -> :158-172 on the ~5 % that survive -> :179-286 five trial phases, first the DF
+//               field, then dense 56-/112-bit slicing by length class -> crc.c:67-82 / :383-406 ->
+//               the filter-independent half of mode_s.c:311-409.  Emits one 8-byte item per trial
+//               phase that can still score >= 0 under some filter state, and marks every address the
+//               filter could ever learn (mode_s.c:717-726) in a 2^24-bit set.
+//   k_prune     drops items that need a filter member which is not in that superset (safe: such a
+//               phase scores < 0 whatever happened before it; demod_2400.c:290,304-310).
+//   sort/unique hipCUB radix sort of the kept items by (offset, phase); distinct offsets ascending.
+//   k_finalize  re-slices those few offsets into full records (5 x 14 message bytes + the signal
 //               power sums of demod_2400.c:345-351) for the host replay.
 //   k_block_sums / k_modeac   convert.c:71-83 block statistics and demod_2400.c:476-622.
 //   k_convert   the stand-alone iq_convert_fn (magnitudes written to HBM) for the drop-in converter.
@@ -18,13 +20,14 @@
 // in the reference's x86-64 build.
 #include "kernels.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <type_traits>
 
 namespace rsb {
 namespace {
 
-constexpr int kTile = 4096;   // scan offsets per workgroup
-constexpr int kHalo = 304;    // look-ahead past the last offset of a tile: 290 needed
+constexpr int kHalo = 304;  // look-ahead past the last offset of a tile: 290 needed, 297 used
 constexpr int kThreads = 256;
 
 // ------------------------------------------------------------------------------------------------
@@ -62,7 +65,7 @@ __device__ __forceinline__ uint32_t stream_mag(const BatchArgs &a, int64_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// demod_2400.c:109-172
+// demod_2400.c:109-172, the whole gate on one offset
 
 __device__ __forceinline__ bool preamble_gate(const uint16_t *p) {
     if (!(p[0] < p[1] && p[12] > p[13])) return false;
@@ -102,18 +105,27 @@ __device__ __forceinline__ bool preamble_gate(const uint16_t *p) {
 // demod_2400.c:48-66 and :179-286 in closed form: bit k of trial phase tp is the sign of correlator
 // (tp + 12k) % 5 at sample 19 + (tp + 12k) / 5 after the preamble start.
 
-__device__ __forceinline__ int slice_corr(const uint16_t *m, int phase) {
+template <int PH>
+__device__ __forceinline__ int corr(const uint16_t *m) {
     const int a = m[0], b = m[1], c = m[2];
+    if constexpr (PH == 0) return 5 * a - 3 * b - 2 * c;
+    if constexpr (PH == 1) return 4 * a - b - 3 * c;
+    if constexpr (PH == 2) return 3 * a + b - 4 * c;
+    if constexpr (PH == 3) return 2 * a + 3 * b - 5 * c;
+    return a + 5 * b - 5 * c - (int)m[3];
+}
+
+__device__ __forceinline__ int slice_corr(const uint16_t *m, int phase) {
     switch (phase) {
-        case 0: return 5 * a - 3 * b - 2 * c;
-        case 1: return 4 * a - b - 3 * c;
-        case 2: return 3 * a + b - 4 * c;
-        case 3: return 2 * a + 3 * b - 5 * c;
-        default: return a + 5 * b - 5 * c - (int)m[3];
+        case 0: return corr<0>(m);
+        case 1: return corr<1>(m);
+        case 2: return corr<2>(m);
+        case 3: return corr<3>(m);
+        default: return corr<4>(m);
     }
 }
 
-// Slices one trial phase starting at d = &S[g + 19]. Bits are packed MSB-first into w[0..3]
+// Generic (per-thread, any phase) slicer: d = &S[g + 19]. Bits are packed MSB-first into w[0..3]
 // (message byte i = bits 31-8*(i&3).. of w[i>>2]). Returns the number of bytes sliced: 14, 7, or 1
 // when the DF is one the demodulator gives up on (demod_2400.c:272-285).
 __device__ int slice_phase(const uint16_t *d, int tp, uint32_t w[4]) {
@@ -145,13 +157,42 @@ __device__ int slice_phase(const uint16_t *d, int tp, uint32_t w[4]) {
     return nbits >> 3;
 }
 
+// The dense slicer: within any 5 consecutive bits every correlator is used exactly once, so a lane
+// can evaluate "correlator 0, 1, 2, 3, 4" in that fixed order -- the same instruction stream for
+// every trial phase -- and only the sample offset and the bit each result lands on differ per lane.
+struct RotSlicer {
+    int off[5];       // sample offset (relative to the group base) at which correlator q is evaluated
+    uint32_t bit[5];  // the bit of the 5-bit group that correlator q decides (MSB = earliest bit)
+    __device__ __forceinline__ explicit RotSlicer(int tp) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int j = ((q + 10 - tp) * 3) % 5;  // bit j of the group uses correlator (tp + 2j) % 5 == q
+            off[q] = (tp + 12 * j) / 5;
+            bit[q] = 16u >> j;
+        }
+    }
+    // five bits starting at bit 5*G of the message; d = &S[g + 19]
+    __device__ __forceinline__ uint32_t group(const uint16_t *d, int G) const {
+        const uint16_t *b = d + 12 * G;
+        uint32_t r = 0;
+        r |= (corr<0>(b + off[0]) > 0) ? bit[0] : 0u;
+        r |= (corr<1>(b + off[1]) > 0) ? bit[1] : 0u;
+        r |= (corr<2>(b + off[2]) > 0) ? bit[2] : 0u;
+        r |= (corr<3>(b + off[3]) > 0) ? bit[3] : 0u;
+        r |= (corr<4>(b + off[4]) > 0) ? bit[4] : 0u;
+        return r;
+    }
+};
+
 __device__ __forceinline__ uint32_t msg_byte(const uint32_t w[4], int i) { return (w[i >> 2] >> (24 - 8 * (i & 3))) & 0xffu; }
 
 // modesChecksum, crc.c:67-82, on the packed words; crcb = crc_table[256] (in LDS)
-__device__ uint32_t syndrome_of(const uint32_t w[4], int nbytes, const uint32_t *crcb) {
+template <int NBYTES>
+__device__ __forceinline__ uint32_t syndrome_of(const uint32_t w[4], const uint32_t *crcb) {
     uint32_t rem = 0;
-    for (int i = 0; i < nbytes - 3; ++i) rem = ((rem << 8) ^ crcb[msg_byte(w, i) ^ (rem >> 16)]) & 0xffffffu;
-    const uint32_t tail = (nbytes == 7) ? ((w[1] >> 8) & 0xffffffu) : (((w[2] & 0xffu) << 16) | (w[3] >> 16));
+#pragma unroll
+    for (int i = 0; i < NBYTES - 3; ++i) rem = ((rem << 8) ^ crcb[msg_byte(w, i) ^ (rem >> 16)]) & 0xffffffu;
+    const uint32_t tail = (NBYTES == 7) ? ((w[1] >> 8) & 0xffffffu) : (((w[2] & 0xffu) << 16) | (w[3] >> 16));
     return rem ^ tail;
 }
 
@@ -178,109 +219,303 @@ __device__ __forceinline__ uint32_t repair_aa(uint32_t addr, uint32_t info) {  /
     return addr;
 }
 
-// The filter-independent half of scoreModesMessage (mode_s.c:311-409): what can this phase's score be?
-__device__ uint32_t classify_phase(const uint32_t w[4], int nbytes, const DeviceTables &t, const uint32_t *crcb, uint32_t *adders) {
-    if (nbytes < 7) return kDead << 24;  // validbits < 56
+constexpr uint32_t kDeadItem = 0xffffffffu;
+constexpr uint32_t kShortDfMask = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);                          // demod_2400.c:274
+constexpr uint32_t kLongDfMask = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21) | (1u << 24);  // demod_2400.c:278
+
+// The filter-independent half of scoreModesMessage (mode_s.c:311-409): which branch does this phase
+// take, and which 24-bit value would it ask the filter about?  combo << 27 | value, or kDeadItem.
+template <int NBYTES>
+__device__ uint32_t classify(const uint32_t w[4], const DeviceTables &t, const uint32_t *crcb, uint32_t *adders) {
     const uint32_t df = w[0] >> 27;
-    if (nbytes == 7 && w[0] == 0 && (w[1] >> 8) == 0) return kDead << 24;  // all-zero message, mode_s.c:325
-    const uint32_t syn = syndrome_of(w, nbytes, crcb);
-    switch (df) {
-        case 0: case 4: case 5: case 16: case 24:  // Address/Parity (25..31 never get this far)
-        case 20: case 21:                          // Comm-B: exact match or nothing (mode_s.c:391-403)
-            return (kNeedCrc << 24) | syn;
-        case 11: {
-            const uint32_t s = syn & 0xffff80u, iid = syn & 0x7fu;
-            uint32_t info = 0;
-            if (s) {
-                info = diagnose(t, 0, s);
-                if (info == 0xffffffffu || (info & 0xff) > 1) return kDead << 24;  // mode_s.c:350-358
-            }
-            const uint32_t addr = repair_aa(w[0] & 0xffffffu, info);
-            if (iid == 0) {
-                if (s == 0) atomicOr(&adders[addr >> 5], 1u << (addr & 31));  // mode_s.c:717-726
-                return (kAlive << 24) | addr;
-            }
-            return (kNeedAddr << 24) | addr;
+    if (NBYTES == 7 && w[0] == 0 && (w[1] >> 8) == 0) return kDeadItem;  // all-zero message, mode_s.c:325
+    const uint32_t syn = syndrome_of<NBYTES>(w, crcb);
+    const uint32_t aa = w[0] & 0xffffffu;
+    if (NBYTES == 7) {
+        if (df != 11) return (kComboApShort << 27) | syn;  // DF0/4/5: Address/Parity
+        const uint32_t s = syn & 0xffff80u, iid = syn & 0x7fu;
+        uint32_t info = 0;
+        if (s) {
+            info = diagnose(t, 0, s);
+            if (info == kDeadItem || (info & 0xff) > 1) return kDeadItem;  // mode_s.c:350-358
         }
-        case 17: case 18: {
-            uint32_t info = 0;
-            if (syn) {
-                info = diagnose(t, 1, syn);
-                if (info == 0xffffffffu) return kDead << 24;
-            }
-            const uint32_t addr = repair_aa(w[0] & 0xffffffu, info);
-            if (df == 17 && syn == 0) atomicOr(&adders[addr >> 5], 1u << (addr & 31));
-            return (kAlive << 24) | addr;
+        const uint32_t addr = repair_aa(aa, info);
+        if (iid == 0) {
+            if (s == 0) atomicOr(&adders[addr >> 5], 1u << (addr & 31));  // mode_s.c:717-726
+            return ((kComboDf11Iid0 + (info & 0xff)) << 27) | addr;
         }
-        default:
-            return kDead << 24;
+        return ((kComboDf11IidX + (info & 0xff)) << 27) | addr;
+    } else {
+        if (df == 16 || df == 24) return (kComboApLong << 27) | syn;
+        if (df == 20 || df == 21) return (kComboCommB << 27) | syn;  // exact match or nothing (mode_s.c:391-403)
+        uint32_t info = 0;  // DF17/18
+        if (syn) {
+            info = diagnose(t, 1, syn);
+            if (info == kDeadItem) return kDeadItem;
+        }
+        const uint32_t addr = repair_aa(aa, info);
+        if (df == 17 && syn == 0) atomicOr(&adders[addr >> 5], 1u << (addr & 31));
+        const uint32_t e = info & 0xff;
+        const uint32_t sub = e ? (2 * e - 1 + (addr != aa)) : 0;
+        return (((df == 17 ? kComboDf17 : kComboDf18) + sub) << 27) | addr;
     }
 }
 
+__device__ __forceinline__ void emit_item(const BatchArgs &a, uint32_t g, uint32_t phase, uint32_t cls) {
+    if (cls == kDeadItem) return;
+    const uint32_t slot = atomicAdd(&a.counters[kCntItems], 1u);
+    if (slot < a.item_cap) a.items[slot] = ItemRec{g, cls | (phase << 24)};
+}
+
+// per-thread path for one trial phase (any length); used when an LDS queue is full
+__device__ void slow_item(const BatchArgs &a, const uint16_t *d, uint32_t g, int phase, const uint32_t *crcb) {
+    uint32_t w[4];
+    const int nbytes = slice_phase(d, phase + 4, w);
+    if (nbytes == 7)
+        emit_item(a, g, phase, classify<7>(w, a.tab, crcb, a.adder_bitmap));
+    else if (nbytes == 14)
+        emit_item(a, g, phase, classify<14>(w, a.tab, crcb, a.adder_bitmap));
+}
+
 // ------------------------------------------------------------------------------------------------
+// the scan kernel
+
+constexpr int kScanT = 8192;                      // scan offsets per tile
+constexpr int kScanThreads = 512;
+constexpr int kScanVecs = (kScanT + kHalo) / 8;   // 16-byte vectors of 8 magnitudes per tile
+constexpr int kTileShift = 2;   // tiles start at S index t*T - 2: then their first IQ sample, t*T - 328, is a multiple of 8
+constexpr int kEdgeCap = 4096;  // edge-pattern candidates of half a tile (at most 2 of any 3 consecutive offsets can pass)
+constexpr int kGateCap = 768;   // gated offsets per tile that go through the dense stages; more take the per-thread path
+constexpr int kListCap = 1536;  // short / long items per tile in the dense stages
+
+struct __attribute__((aligned(16))) ScanShared {
+    uint16_t m[kScanT + kHalo];
+    uint16_t lut[16384];
+    uint16_t eq[kEdgeCap];
+    uint16_t gq[kGateCap];
+    uint16_t lst[2][kListCap];
+    uint32_t crcb[256];
+    uint32_t cnt[6];  // edge candidates (first half), gated, short items, long items, edge candidates (second half)
+};
+
+__device__ __forceinline__ uint32_t uc8_pair(uint32_t x, const uint16_t *lut) {
+    // two UC8 samples (I0 Q0 I1 Q1) -> two magnitudes. |v - 127.5| - 0.5 per byte, then the folded
+    // 128 x 128 table; the XOR spreads rows over LDS banks (small signals otherwise hit few banks)
+    const uint32_t t = (~x >> 7) & 0x01010101u;
+    const uint32_t f = (x ^ ((t << 7) - t)) & 0x7f7f7f7fu;
+    uint32_t i0 = (f & 0x7f) | ((f >> 1) & 0x3f80);
+    uint32_t i1 = ((f >> 16) & 0x7f) | ((f >> 17) & 0x3f80);
+    i0 ^= (i0 >> 6) & 0x3e;
+    i1 ^= (i1 >> 6) & 0x3e;
+    return (uint32_t)lut[i0] | ((uint32_t)lut[i1] << 16);
+}
 
 template <int FMT>
-__global__ __launch_bounds__(kThreads) void k_scan(const BatchArgs a) {
-    __shared__ uint16_t m[kTile + kHalo];
-    __shared__ uint16_t queue[kTile];
-    __shared__ uint32_t crcb[256];
-    __shared__ uint32_t qn;
+__device__ __forceinline__ uint32_t sc16_pair(uint4 v, int which) {
+    constexpr float scale = (FMT == kFmtSC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+    const uint32_t a = which ? v.z : v.x, b = which ? v.w : v.y;
+    const uint32_t m0 = float_mag((float)(short)(a & 0xffff) * scale, (float)(short)(a >> 16) * scale);
+    const uint32_t m1 = float_mag((float)(short)(b & 0xffff) * scale, (float)(short)(b >> 16) * scale);
+    return m0 | (m1 << 16);
+}
 
-    const uint32_t tid = threadIdx.x;
-    const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
-    const uint32_t nvalid = (uint32_t)((a.n - t0 < (uint64_t)kTile) ? (a.n - t0) : (uint64_t)kTile);
+template <int FMT>
+__global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
+    __shared__ ScanShared sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
 
-    for (uint32_t i = tid; i < kTile + kHalo; i += kThreads) m[i] = (uint16_t)stream_mag<FMT>(a, (int64_t)(t0 + i));
-    crcb[tid] = a.tab.crc_bytes[tid];
-    if (tid == 0) qn = 0;
-    __syncthreads();
-
-    for (uint32_t j = tid; j < nvalid; j += kThreads)
-        if (preamble_gate(&m[j])) queue[atomicAdd(&qn, 1u)] = (uint16_t)j;
-    __syncthreads();
-
-    const uint32_t ncand = qn;
-    if (tid == 0 && ncand) atomicAdd(&a.counters[kCntGated], ncand);
-
-    for (uint32_t c = tid; c < ncand; c += kThreads) {
-        const uint32_t j = queue[c];
-        KeyRec rec;
-        rec.g = (uint32_t)(t0 + j);
-        bool live = false;
-        for (int p = 0; p < 5; ++p) {
-            uint32_t w[4];
-            const int nbytes = slice_phase(&m[j + 19], p + 4, w);
-            rec.key[p] = classify_phase(w, nbytes, a.tab, crcb, a.adder_bitmap);
-            live |= (rec.key[p] >> 24) != kDead;
+    if (FMT == kFmtUC8)
+        for (uint32_t i = tid; i < 16384; i += kScanThreads) {
+            const uint32_t ai = i & 127, aq = i >> 7;
+            sh.lut[i ^ ((aq & 31) << 1)] = a.tab.uc8_lut[((128 + aq) << 8) | (128 + ai)];
         }
-        if (live || a.emit_dead) {
-            const uint32_t slot = atomicAdd(&a.counters[kCntKeys], 1u);
-            if (slot < a.key_cap) a.keys[slot] = rec;
+    if (tid < 256) sh.crcb[tid] = a.tab.crc_bytes[tid];
+
+    const uint64_t ntiles = (a.n + kTileShift + kScanT - 1) / kScanT;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t s0 = (int64_t)(t * kScanT) - kTileShift;  // S index of m[0]
+        __syncthreads();  // previous tile fully consumed; LUT ready
+        if (tid < 6) sh.cnt[tid] = 0;
+
+        // ---- convert.c: tile + halo -> magnitudes in LDS
+        for (int v = tid; v < kScanVecs; v += kScanThreads) {
+            const int64_t s = s0 + 8 * v, q = s - (int64_t)kTrailing;
+            uint4 o;
+            if ((FMT == kFmtUC8) && a.iq_aligned && q >= 0 && q + 8 <= (int64_t)a.n) {
+                const uint4 x = *(const uint4 *)((const uint8_t *)a.iq + 2 * q);
+                o = make_uint4(uc8_pair(x.x, sh.lut), uc8_pair(x.y, sh.lut), uc8_pair(x.z, sh.lut), uc8_pair(x.w, sh.lut));
+            } else if ((FMT == kFmtSC16 || FMT == kFmtSC16Q11) && a.iq_aligned && q >= 0 && q + 8 <= (int64_t)a.n) {
+                const uint4 *src = (const uint4 *)((const uint8_t *)a.iq + 4 * q);
+                const uint4 x0 = src[0], x1 = src[1];
+                o = make_uint4(sc16_pair<FMT>(x0, 0), sc16_pair<FMT>(x0, 1), sc16_pair<FMT>(x1, 0), sc16_pair<FMT>(x1, 1));
+            } else {
+                uint32_t e[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[k] = stream_mag<FMT>(a, s + k);
+                o = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+            }
+            ((uint4 *)sh.m)[v] = o;
+        }
+        __syncthreads();
+
+        for (int h = 0; h < 2; ++h) {
+            // ---- demod_2400.c:109-155, edge patterns only, 64 lanes x 8 consecutive offsets per ballot
+            {
+                const int base = h * (kScanT / 2) + (int)tid * 8;
+                uint32_t w[22];
+                const uint4 *src = (const uint4 *)&sh.m[base];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const uint4 v = src[q];
+                    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (q * 8 + e * 2 < 22) w[q * 8 + e * 2] = d[e] & 0xffff;
+                        if (q * 8 + e * 2 + 1 < 22) w[q * 8 + e * 2 + 1] = d[e] >> 16;
+                    }
+                }
+                uint64_t L[21], G[21];  // L[j]: S[base+j] < S[base+j+1] per lane, G[j]: >
+#pragma unroll
+                for (int j = 0; j < 21; ++j) {
+                    L[j] = __ballot(w[j] < w[j + 1]);
+                    G[j] = __ballot(w[j] > w[j + 1]);
+                }
+                uint64_t E[8];
+                uint32_t total = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint64_t *l = &L[k], *g = &G[k];
+                    // the five peak patterns of :112-151 OR-ed together, gated by the quick check of :109
+                    const uint64_t A = g[1] & l[2], B = l[3] & g[4], C = l[8] & g[9], D = g[10] & l[11];
+                    const uint64_t p12 = A & g[3] & C & (l[10] | l[11]);
+                    const uint64_t p345 = ((A & g[4] & l[8]) | (B & l[9] & (g[1] | g[2]))) & D;
+                    E[k] = (p12 | p345) & l[0] & g[12];
+                    total += __popcll(E[k]);
+                }
+                if (total) {
+                    uint32_t wbase = 0;
+                    if (lane == 0) wbase = atomicAdd(&sh.cnt[4 * h], total);
+                    wbase = __builtin_amdgcn_readfirstlane(wbase);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if ((E[k] >> lane) & 1) {
+                            const uint32_t pos = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(E[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E[k], 0));
+                            if (pos < (uint32_t)kEdgeCap) sh.eq[pos] = (uint16_t)(base + k);
+                        }
+                        wbase += __popcll(E[k]);
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- the whole gate (:109-172) on the edge candidates; survivors go to the gated queue
+            {
+                const uint32_t neq = min(sh.cnt[4 * h], (uint32_t)kEdgeCap);
+                for (uint32_t c = tid; c < neq; c += kScanThreads) {
+                    const uint32_t j = sh.eq[c];
+                    const int64_t g = s0 + j;
+                    if (g < 0 || (uint64_t)g >= a.n) continue;
+                    if (!preamble_gate(&sh.m[j])) continue;
+                    if (a.emit_dead) {
+                        const uint32_t slot = atomicAdd(&a.counters[kCntItems], 1u);
+                        if (slot < a.item_cap) a.items[slot] = ItemRec{(uint32_t)g, (kComboMarker << 27) | (7u << 24)};
+                    }
+                    const uint32_t pos = atomicAdd(&sh.cnt[1], 1u);
+                    if (pos < (uint32_t)kGateCap) {
+                        sh.gq[pos] = (uint16_t)j;
+                    } else {
+                        atomicAdd(&a.counters[kCntSlowPath], 1u);
+                        for (int p = 0; p < 5; ++p) slow_item(a, &sh.m[j + 19], (uint32_t)g, p, sh.crcb);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        const uint32_t ngated = sh.cnt[1];
+        const uint32_t ngq = min(ngated, (uint32_t)kGateCap);
+        if (tid == 0 && ngated) atomicAdd(&a.counters[kCntGated], ngated);
+
+        // ---- first five bits (the DF) of every (offset, trial phase): which length class? (:272-285)
+        for (uint32_t i = tid; i < 5 * ngq; i += kScanThreads) {
+            const uint32_t cand = i / 5, phase = i - 5 * cand;
+            const uint32_t j = sh.gq[cand];
+            const RotSlicer rs((int)phase + 4);
+            const uint32_t df = rs.group(&sh.m[j + 19], 0);
+            const uint32_t cls = ((kShortDfMask >> df) & 1) ? 0u : (((kLongDfMask >> df) & 1) ? 1u : 2u);
+            if (cls < 2) {
+                const uint32_t pos = atomicAdd(&sh.cnt[2 + cls], 1u);
+                if (pos < (uint32_t)kListCap) {
+                    sh.lst[cls][pos] = (uint16_t)i;
+                } else {
+                    atomicAdd(&a.counters[kCntSlowPath], 1u);
+                    slow_item(a, &sh.m[j + 19], (uint32_t)(s0 + j), (int)phase, sh.crcb);
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t ns = min(sh.cnt[2], (uint32_t)kListCap), nl = min(sh.cnt[3], (uint32_t)kListCap);
+
+        // ---- 56-bit frames: 12 groups of 5 bits
+        {
+            for (uint32_t c = tid; c < ns; c += kScanThreads) {
+                const uint32_t i = sh.lst[0][c], cand = i / 5, phase = i - 5 * cand;
+                const uint32_t j = sh.gq[cand];
+                const RotSlicer rs((int)phase + 4);
+                const uint16_t *d = &sh.m[j + 19];
+                uint64_t acc = 0;
+#pragma unroll
+                for (int G = 0; G < 12; ++G) acc = (acc << 5) | rs.group(d, G);
+                acc <<= 4;  // message bit 0 -> bit 63; bits 7..4 hold the four extra bits sliced
+                uint32_t w[4] = {(uint32_t)(acc >> 32), (uint32_t)acc & 0xffffff00u, 0, 0};
+                emit_item(a, (uint32_t)(s0 + j), phase, classify<7>(w, a.tab, sh.crcb, a.adder_bitmap));
+            }
+        }
+        // ---- 112-bit frames: 23 groups of 5 bits
+        {
+            for (uint32_t c = tid; c < nl; c += kScanThreads) {
+                const uint32_t i = sh.lst[1][c], cand = i / 5, phase = i - 5 * cand;
+                const uint32_t j = sh.gq[cand];
+                const RotSlicer rs((int)phase + 4);
+                const uint16_t *d = &sh.m[j + 19];
+                uint64_t hi = 0, lo = 0;  // 128-bit shift register
+#pragma unroll
+                for (int G = 0; G < 23; ++G) {
+                    hi = (hi << 5) | (lo >> 59);
+                    lo = (lo << 5) | rs.group(d, G);
+                }
+                hi = (hi << 13) | (lo >> 51);  // message bit 0 -> bit 127; bits 15..13 hold the three extra bits
+                lo <<= 13;
+                uint32_t w[4] = {(uint32_t)(hi >> 32), (uint32_t)hi, (uint32_t)(lo >> 32), (uint32_t)lo & 0xffff0000u};
+                emit_item(a, (uint32_t)(s0 + j), phase, classify<14>(w, a.tab, sh.crcb, a.adder_bitmap));
+            }
         }
     }
 }
 
 __global__ __launch_bounds__(kThreads) void k_prune(const BatchArgs a) {
-    uint32_t nkeys = a.counters[kCntKeys];
-    if (nkeys > a.key_cap) nkeys = a.key_cap;
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < nkeys; i += gridDim.x * kThreads) {
-        const KeyRec rec = a.keys[i];
-        bool keep = a.keep_all != 0;
-        for (int p = 0; p < 5 && !keep; ++p) {
-            const uint32_t cls = rec.key[p] >> 24, v = rec.key[p] & 0xffffffu;
-            if (cls == kAlive)
-                keep = true;
-            else if (cls == kNeedCrc || cls == kNeedAddr)
-                keep = (a.adder_bitmap[v >> 5] >> (v & 31)) & 1u;
-        }
+    uint32_t n = a.counters[kCntItems];
+    if (n > a.item_cap) n = a.item_cap;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const ItemRec rec = a.items[i];
+        const uint32_t combo = item_combo(rec.info), v = item_value(rec.info);
+        bool keep = a.keep_all != 0 || combo == kComboMarker || !combo_needs_member(combo);
+        if (!keep) keep = (a.adder_bitmap[v >> 5] >> (v & 31)) & 1u;
         if (keep) {
-            const uint32_t slot = atomicAdd(&a.counters[kCntSurvivors], 1u);
-            if (slot < a.surv_cap) a.surv_g[slot] = rec.g;
+            const uint32_t slot = atomicAdd(&a.counters[kCntSurvItems], 1u);
+            if (slot < a.item_cap) {
+                a.skeys[0][slot] = ((uint64_t)rec.g << 3) | item_phase(rec.info);
+                a.sinfo[0][slot] = rec.info;
+            }
         }
     }
 }
 
-// one wavefront per survivor
+__global__ __launch_bounds__(kThreads) void k_keys_to_g(const uint64_t *keys, uint32_t *g, uint32_t n) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) g[i] = (uint32_t)(keys[i] >> 3);
+}
+
+// one wavefront per distinct surviving offset
 template <int FMT>
 __global__ __launch_bounds__(64) void k_finalize(const BatchArgs a) {
     __shared__ uint16_t m[kHalo];
@@ -321,6 +556,8 @@ __global__ __launch_bounds__(64) void k_finalize(const BatchArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Mode A/C
+
+constexpr int kTile = 4096;
 
 // convert.c:71-83: per 131072-block sums over the block's NEW samples (integer converters only)
 template <int FMT>
@@ -472,18 +709,51 @@ inline unsigned tiles_of(uint64_t n) { return (unsigned)((n + kTile - 1) / kTile
 
 }  // namespace
 
-hipError_t launch_scan(const BatchArgs &a, hipStream_t s) {
+int scan_grid_size(int device) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 512;
+    return 2 * p.multiProcessorCount;  // two 512-thread workgroups (~64 KB of LDS each) per CU
+}
+
+hipError_t launch_scan(const BatchArgs &a, int grid, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
+    const uint64_t ntiles = (a.n + kTileShift + kScanT - 1) / kScanT;
+    if ((uint64_t)grid > ntiles) grid = (int)ntiles;
     return by_format(a.fmt, [&](auto F) {
-        hipLaunchKernelGGL(k_scan<decltype(F)::value>, dim3(tiles_of(a.n)), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL(k_scan<decltype(F)::value>, dim3(grid), dim3(kScanThreads), 0, s, a);
         return hipGetLastError();
     });
 }
 
-hipError_t launch_prune_finalize(const BatchArgs &a, hipStream_t s) {
+hipError_t launch_prune(const BatchArgs &a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_prune, dim3(1024), dim3(kThreads), 0, s, a);
-    hipError_t e = hipGetLastError();
+    return hipGetLastError();
+}
+
+size_t sort_temp_bytes(uint32_t max_items) {
+    size_t sort_bytes = 0, uniq_bytes = 0;
+    hipcub::DoubleBuffer<uint64_t> k(nullptr, nullptr);
+    hipcub::DoubleBuffer<uint32_t> v(nullptr, nullptr);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k, v, (int)max_items, 0, 35);
+    (void)hipcub::DeviceSelect::Unique(nullptr, uniq_bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)max_items);
+    return (sort_bytes > uniq_bytes ? sort_bytes : uniq_bytes) + 256;
+}
+
+hipError_t launch_sort_unique_finalize(const BatchArgs &a, uint32_t n_items, void *temp, size_t temp_bytes, int *sorted_buf, hipStream_t s) {
+    *sorted_buf = 0;
+    if (n_items == 0) return hipMemsetAsync(&a.counters[kCntSurvivors], 0, sizeof(uint32_t), s);
+    hipcub::DoubleBuffer<uint64_t> k(a.skeys[0], a.skeys[1]);
+    hipcub::DoubleBuffer<uint32_t> v(a.sinfo[0], a.sinfo[1]);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k, v, (int)n_items, 0, 35, s);
+    if (e != hipSuccess) return e;
+    *sorted_buf = (k.Current() == a.skeys[1]) ? 1 : 0;
+    // distinct offsets, ascending: the other key buffer is free now and serves as scratch for g
+    uint32_t *gtmp = (uint32_t *)a.skeys[*sorted_buf ^ 1];
+    hipLaunchKernelGGL(k_keys_to_g, dim3(512), dim3(kThreads), 0, s, k.Current(), gtmp, n_items);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = hipcub::DeviceSelect::Unique(temp, temp_bytes, gtmp, a.surv_g, &a.counters[kCntSurvivors], (int)n_items, s);
     if (e != hipSuccess) return e;
     return by_format(a.fmt, [&](auto F) {
         hipLaunchKernelGGL(k_finalize<decltype(F)::value>, dim3(8192), dim3(64), 0, s, a);

@@ -14,10 +14,12 @@ enum : int { kFmtUC8 = 0, kFmtSC16 = 1, kFmtSC16Q11 = 2, kFmtMag16 = 3 };
 
 // device counters (one uint32 each)
 enum : int {
-    kCntKeys = 0,      // key records appended by the scan kernel
-    kCntSurvivors,     // survivors appended by the prune kernel
+    kCntItems = 0,     // item records appended by the scan kernel
+    kCntSurvItems,     // items kept by the prune kernel
     kCntAc,            // Mode A/C candidates
     kCntGated,         // offsets that passed the preamble gate
+    kCntSurvivors,     // distinct offsets among the kept items (written by the unique step)
+    kCntSlowPath,      // candidates / items that overflowed an LDS queue and took the per-thread path
     kCntCount = 8
 };
 
@@ -36,11 +38,14 @@ struct BatchArgs {
     const void *carry;     // 326 samples of the same format (the tail of the previous batch)
     int carry_valid;       // 0: the 326 leading magnitudes are zero (sdr_ifile.c:200-204)
     int fmt;
+    int iq_aligned;        // iq is 16-byte aligned: the scan kernel may use vector loads
     uint64_t n;
     DeviceTables tab;
-    KeyRec *keys;
-    uint32_t key_cap;
-    uint32_t *surv_g;      // offsets of the candidates kept by the prune kernel
+    ItemRec *items;
+    uint32_t item_cap;
+    uint64_t *skeys[2];    // kept items: sort key g << 3 | phase (ping-pong buffers for the radix sort)
+    uint32_t *sinfo[2];    // ... and their info words
+    uint32_t *surv_g;      // distinct offsets of the kept items, ascending
     Survivor *survivors;
     uint32_t surv_cap;
     AcCand *ac;
@@ -48,12 +53,17 @@ struct BatchArgs {
     uint32_t *adder_bitmap;  // 2^24 bits: superset of every address the filter can hold
     uint32_t *counters;
     uint64_t *block_sums;    // per 131072-block: sum(mag), sum(mag^2) over its new samples
-    int emit_dead;           // also keep gated offsets whose five phases are all dead (exact stats)
-    int keep_all;            // prune keeps every key record (filter owned by the caller)
+    int emit_dead;           // also emit a marker item per gated offset (exact demod statistics)
+    int keep_all;            // prune keeps every item (filter owned by the caller)
 };
 
-hipError_t launch_scan(const BatchArgs &a, hipStream_t s);
-hipError_t launch_prune_finalize(const BatchArgs &a, hipStream_t s);
+int scan_grid_size(int device);
+hipError_t launch_scan(const BatchArgs &a, int grid, hipStream_t s);
+hipError_t launch_prune(const BatchArgs &a, hipStream_t s);
+// sorts the n_items kept items by (g, phase), derives the ascending list of distinct offsets
+// (count -> counters[kCntSurvivors]) and re-slices each of them into a Survivor record
+size_t sort_temp_bytes(uint32_t max_items);
+hipError_t launch_sort_unique_finalize(const BatchArgs &a, uint32_t n_items, void *temp, size_t temp_bytes, int *sorted_buf, hipStream_t s);
 hipError_t launch_modeac(const BatchArgs &a, hipStream_t s);
 hipError_t launch_convert(int fmt, const void *iq, uint16_t *mag, uint64_t n, const uint16_t *lut, uint64_t *sums, hipStream_t s);
 

@@ -12,6 +12,12 @@
 
 #include "../../include/readsb_amd.h"
 
+#if defined(__HIPCC__)
+#define RSB_HD __host__ __device__
+#else
+#define RSB_HD
+#endif
+
 namespace rsb {
 
 constexpr uint32_t kBlock = RSB_BLOCK_SAMPLES;
@@ -19,18 +25,30 @@ constexpr uint32_t kTrailing = RSB_TRAILING_SAMPLES;
 
 // ---- records shared with the kernels (kernels.hip includes this header) -------------------
 
-// per-phase classes in a key record (what the phase's score can become, over all filter states)
-enum : uint32_t {
-    kDead = 0,        // -2 whatever the filter holds
-    kNeedCrc = 1,     // Address/Parity DFs: alive iff the 24-bit syndrome is a filter member
-    kNeedAddr = 2,    // DF11 with IID != 0: alive iff the (repaired) AA is a filter member
-    kAlive = 3        // DF17/18 correctable, DF11 IID == 0 correctable: score >= 0 regardless
-};
-
-struct KeyRec {       // 24 B, written by the scan kernel for every gated offset it keeps
+// One sliced trial phase of a gated scan offset that can still score >= 0 under some filter state.
+// info = combo << 27 | phase << 24 | value; combo says which branch of scoreModesMessage /
+// decodeModesMessage (mode_s.c:330-408, 445-555) the phase takes and how many bits the syndrome
+// repair flips; value is the 24-bit number the ICAO filter is asked about (the CRC syndrome for
+// Address/Parity and Comm-B, the repaired AA otherwise).
+struct ItemRec {      // 8 B, written by the scan kernel
     uint32_t g;       // batch-relative scan offset
-    uint32_t key[5];  // class << 24 | 24-bit value, one per try_phase 4..8
+    uint32_t info;
 };
+enum : uint32_t {
+    kComboApShort = 0,   // DF0/4/5
+    kComboApLong = 1,    // DF16/24
+    kComboCommB = 2,     // DF20/21
+    kComboDf11Iid0 = 3,  // + errors (0..1)
+    kComboDf11IidX = 5,  // + errors (0..1)
+    kComboDf17 = 7,      // 7: clean, 8/9: 1 bit (AA same / changed), 10/11: 2 bits (same / changed)
+    kComboDf18 = 12,     // same layout as DF17
+    kComboMarker = 31    // "this offset passed the gate" (exact-statistics mode only)
+};
+RSB_HD inline uint32_t item_combo(uint32_t info) { return info >> 27; }
+RSB_HD inline uint32_t item_phase(uint32_t info) { return (info >> 24) & 7u; }
+RSB_HD inline uint32_t item_value(uint32_t info) { return info & 0xffffffu; }
+// does this combo need a filter member to score >= 0?
+RSB_HD inline bool combo_needs_member(uint32_t c) { return c <= kComboCommB || c == kComboDf11IidX || c == kComboDf11IidX + 1; }
 
 struct Survivor {     // 96 B, written by the finalize kernel
     uint32_t g;
@@ -40,7 +58,7 @@ struct Survivor {     // 96 B, written by the finalize kernel
     uint64_t pow134;      // sum of mag^2 over 134 / 268 samples from S[g+19] (demod_2400.c:345-351)
     uint64_t pow268;
 };
-static_assert(sizeof(KeyRec) == 24, "KeyRec layout");
+static_assert(sizeof(ItemRec) == 8, "ItemRec layout");
 static_assert(sizeof(Survivor) == 96, "Survivor layout");
 
 struct AcCand {       // 12 B, Mode A/C candidate that passed every test of demod_2400.c:535-622
@@ -55,11 +73,6 @@ struct DevSyndromeTable {
     std::vector<uint32_t> vals;  // errors | bit0 << 8 | bit1 << 16
     uint32_t mask = 0;
 };
-#if defined(__HIPCC__)
-#define RSB_HD __host__ __device__
-#else
-#define RSB_HD
-#endif
 RSB_HD inline uint32_t syndrome_hash(uint32_t s, uint32_t mask) { return ((s * 0x9E3779B1u) >> 12) & mask; }
 
 // ---- CRC ------------------------------------------------------------------------------------
