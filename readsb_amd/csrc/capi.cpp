@@ -53,6 +53,7 @@ int setup_device(rsb_ctx *c) {
     int rc;
     if ((rc = upload(c, &c->d_lut, uc8_magnitude_lut(), 65536)) != RSB_OK) return rc;
     if ((rc = upload(c, &c->d_crc_bytes, CrcTables::byte_table(), 256)) != RSB_OK) return rc;
+    if ((rc = upload(c, &c->d_sbs, CrcTables::single_bit_syndromes(), 112)) != RSB_OK) return rc;
     for (int w = 0; w < 2; ++w) {
         DevSyndromeTable t = c->replay.crc().device_table(w == 0 ? 56 : 112);
         c->syn_mask[w] = t.mask;
@@ -66,19 +67,26 @@ int setup_device(rsb_ctx *c) {
     uint64_t cap = nmax / div;
     if (cap < 4096) cap = 4096;
     if (cap > 0x7fffffffull) cap = 0x7fffffffull;
-    c->item_cap = (uint32_t)cap;
+    // scan output: wave-private regions need head-room for uneven traffic (4x the kept-item capacity)
+    c->surv_item_cap = (uint32_t)cap;
+    c->item_cap = (uint32_t)(cap * 4 > 0x7fffffffull ? 0x7fffffffull : cap * 4);
+    if (c->item_cap < 65536) c->item_cap = 65536;
     c->surv_cap = (uint32_t)(cap / 4 < 4096 ? 4096 : cap / 4);
     c->ac_cap = (uint32_t)(cap / 4 < 4096 ? 4096 : cap / 4);
     c->nblocks_cap = (nmax + kBlock - 1) / kBlock + 1;
     c->scan_grid = scan_grid_size(c->cfg.device);
+    if (const char *e = std::getenv("RSB_STAGE_LIMIT")) c->stage_limit = std::atoi(e);  // ablation timing only
+    if (const char *e = std::getenv("RSB_ABL")) c->debug_flags = std::atoi(e);
+    if (const char *e = std::getenv("RSB_SCAN_GRID")) c->scan_grid = std::atoi(e);
     HIP_TRY(c, hipMalloc((void **)&c->d_items, (size_t)c->item_cap * sizeof(ItemRec)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_region_counts, (size_t)c->scan_grid * 16 * sizeof(uint32_t)));
     for (int w = 0; w < 2; ++w) {
-        HIP_TRY(c, hipMalloc((void **)&c->d_skeys[w], (size_t)c->item_cap * sizeof(uint64_t)));
-        HIP_TRY(c, hipMalloc((void **)&c->d_sinfo[w], (size_t)c->item_cap * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_skeys[w], (size_t)c->surv_item_cap * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_sinfo[w], (size_t)c->surv_item_cap * sizeof(uint32_t)));
     }
-    c->sort_temp_bytes = sort_temp_bytes(c->item_cap);
+    c->sort_temp_bytes = sort_temp_bytes(c->surv_item_cap);
     HIP_TRY(c, hipMalloc(&c->d_sort_temp, c->sort_temp_bytes));
-    HIP_TRY(c, hipMalloc((void **)&c->d_surv_g, (size_t)c->item_cap * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_surv_g, (size_t)c->surv_item_cap * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_surv, (size_t)c->surv_cap * sizeof(Survivor)));
     HIP_TRY(c, hipMalloc((void **)&c->d_ac, (size_t)c->ac_cap * sizeof(AcCand)));
     HIP_TRY(c, hipMalloc((void **)&c->d_bitmap, (1u << 24) / 8));
@@ -142,8 +150,8 @@ int rsb_create(const rsb_config *cfg, rsb_ctx **out) {
 void rsb_destroy(rsb_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
-    void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1],
-                    c->d_items, c->d_skeys[0], c->d_skeys[1], c->d_sinfo[0], c->d_sinfo[1], c->d_sort_temp, c->d_surv_g, c->d_surv, c->d_ac, c->d_bitmap, c->d_counters, c->d_block_sums, c->d_carry,
+    void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1],
+                    c->d_items, c->d_region_counts, c->d_skeys[0], c->d_skeys[1], c->d_sinfo[0], c->d_sinfo[1], c->d_sort_temp, c->d_surv_g, c->d_surv, c->d_ac, c->d_bitmap, c->d_counters, c->d_block_sums, c->d_carry,
                     c->d_stage, c->d_mag, c->d_sums};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -200,6 +208,7 @@ int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) 
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     BatchArgs a = c->batch_args(iq_dev, nsamples, c->cfg.input_format);
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCntCount * sizeof(uint32_t), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_region_counts, 0, (size_t)a.n_regions * sizeof(uint32_t), s));
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     HIP_TRY(c, launch_scan(a, c->scan_grid, s));
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
@@ -231,10 +240,10 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     uint32_t cnt[kCntCount];
     HIP_TRY(c, hipMemcpyAsync(cnt, c->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    if (cnt[kCntItems] > c->item_cap || cnt[kCntAc] > c->ac_cap) {
+    if (cnt[kCntOverflow] || cnt[kCntSurvItems] > c->surv_item_cap || cnt[kCntAc] > c->ac_cap) {
         char buf[200];
-        std::snprintf(buf, sizeof(buf), "device queue overflow: items %u/%u modeac %u/%u (lower rsb_config.queue_div)", cnt[kCntItems],
-                      c->item_cap, cnt[kCntAc], c->ac_cap);
+        std::snprintf(buf, sizeof(buf), "device queue overflow: %u item regions, kept items %u/%u, modeac %u/%u (lower rsb_config.queue_div)",
+                      cnt[kCntOverflow], cnt[kCntSurvItems], c->surv_item_cap, cnt[kCntAc], c->ac_cap);
         c->err = buf;
         c->finished = true;
         return RSB_EOVERFLOW;
@@ -283,7 +292,7 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     rsb_stats &st = c->replay.stats();
     st.samples_processed += c->pending_n;
     st.gated_offsets += cnt[kCntGated];
-    st.live_candidates += cnt[kCntItems];
+    st.live_candidates += cnt[kCntItemsTotal];
     st.survivors += cnt[kCntSurvivors];
     st.modeac_candidates += cnt[kCntAc];
 

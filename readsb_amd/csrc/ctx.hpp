@@ -22,12 +22,14 @@ struct rsb_ctx {
     // read-only device tables
     uint16_t *d_lut = nullptr;
     uint32_t *d_crc_bytes = nullptr;
+    uint32_t *d_sbs = nullptr;
     uint32_t *d_syn_keys[2] = {nullptr, nullptr};
     uint32_t *d_syn_vals[2] = {nullptr, nullptr};
     uint32_t syn_mask[2] = {0, 0};
 
     // device work buffers
     rsb::ItemRec *d_items = nullptr;
+    uint32_t *d_region_counts = nullptr;
     uint64_t *d_skeys[2] = {nullptr, nullptr};
     uint32_t *d_sinfo[2] = {nullptr, nullptr};
     uint32_t *d_surv_g = nullptr;
@@ -35,9 +37,11 @@ struct rsb_ctx {
     rsb::AcCand *d_ac = nullptr;
     void *d_sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
-    uint32_t item_cap = 0, surv_cap = 0, ac_cap = 0;
+    uint32_t item_cap = 0, surv_item_cap = 0, surv_cap = 0, ac_cap = 0;
     int scan_grid = 512;
     int sorted_buf = 0;
+    int stage_limit = 99;
+    int debug_flags = 0;
     uint32_t *d_bitmap = nullptr;
     uint32_t *d_counters = nullptr;
     uint64_t *d_block_sums = nullptr;
@@ -73,6 +77,7 @@ struct rsb_ctx {
         a.n = n;
         a.tab.uc8_lut = d_lut;
         a.tab.crc_bytes = d_crc_bytes;
+        a.tab.sbs = d_sbs;
         for (int w = 0; w < 2; ++w) {
             a.tab.syn_keys[w] = d_syn_keys[w];
             a.tab.syn_vals[w] = d_syn_vals[w];
@@ -81,7 +86,16 @@ struct rsb_ctx {
         a.tab.nfix = cfg.fix_bits;
         a.iq_aligned = ((uintptr_t)iq % 16 == 0) ? 1 : 0;
         a.items = d_items;
-        a.item_cap = item_cap;
+        {
+            // one item region per wavefront that will actually run (launch_scan shrinks the grid for small batches)
+            const uint64_t nstrips = (n + 2 + 2047) / 2048, need = (nstrips + 15) / 16;
+            const uint32_t grid = (uint32_t)(need < (uint64_t)scan_grid ? (need ? need : 1) : (uint64_t)scan_grid);
+            a.n_regions = grid * 16u;
+        }
+        a.shared_cap = item_cap / 16;
+        a.item_region = (item_cap - a.shared_cap) / a.n_regions;
+        a.region_counts = d_region_counts;
+        a.surv_item_cap = surv_item_cap;
         for (int w = 0; w < 2; ++w) {
             a.skeys[w] = d_skeys[w];
             a.sinfo[w] = d_sinfo[w];
@@ -96,6 +110,8 @@ struct rsb_ctx {
         a.block_sums = d_block_sums;
         a.emit_dead = 0;
         a.keep_all = 0;
+        a.stage_limit = stage_limit;
+        a.debug_flags = debug_flags;
         return a;
     }
 };

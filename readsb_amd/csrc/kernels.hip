@@ -67,38 +67,43 @@ __device__ __forceinline__ uint32_t stream_mag(const BatchArgs &a, int64_t s) {
 // ------------------------------------------------------------------------------------------------
 // demod_2400.c:109-172, the whole gate on one offset
 
-__device__ __forceinline__ bool preamble_gate(const uint16_t *p) {
-    if (!(p[0] < p[1] && p[12] > p[13])) return false;
-    int high;
-    uint32_t sig, noise;
-    if (p[1] > p[2] && p[2] < p[3] && p[3] > p[4] && p[8] < p[9] && p[9] > p[10] && p[10] < p[11]) {
-        high = (p[1] + p[3] + p[9] + p[11] + p[12]) / 4;
-        sig = p[1] + p[3] + p[9];
-        noise = p[5] + p[6] + p[7];
-    } else if (p[1] > p[2] && p[2] < p[3] && p[3] > p[4] && p[8] < p[9] && p[9] > p[10] && p[11] < p[12]) {
-        high = (p[1] + p[3] + p[9] + p[12]) / 4;
-        sig = p[1] + p[3] + p[9] + p[12];
-        noise = p[5] + p[6] + p[7] + p[8];
-    } else if (p[1] > p[2] && p[2] < p[3] && p[4] > p[5] && p[8] < p[9] && p[10] > p[11] && p[11] < p[12]) {
-        high = (p[1] + p[3] + p[4] + p[9] + p[10] + p[12]) / 4;
-        sig = p[1] + p[12];
-        noise = p[6] + p[7];
-    } else if (p[1] > p[2] && p[3] < p[4] && p[4] > p[5] && p[9] < p[10] && p[10] > p[11] && p[11] < p[12]) {
-        high = (p[1] + p[4] + p[10] + p[12]) / 4;
-        sig = p[1] + p[4] + p[10] + p[12];
-        noise = p[5] + p[6] + p[7] + p[8];
-    } else if (p[2] > p[3] && p[3] < p[4] && p[4] > p[5] && p[9] < p[10] && p[10] > p[11] && p[11] < p[12]) {
-        high = (p[1] + p[2] + p[4] + p[10] + p[12]) / 4;
-        sig = p[4] + p[10] + p[12];
-        noise = p[6] + p[7] + p[8];
-    } else {
-        return false;
+__device__ __forceinline__ bool preamble_gate(const uint16_t *m, int e) {
+    // all 19 samples first (independent LDS reads), then straight-line selects: the first matching
+    // pattern of :112-151 decides high / signal / noise
+    int p[19];
+    {
+        // 19 samples from 11 aligned dwords (the array base is 4-byte aligned; e = sample index)
+        const uint32_t *q = (const uint32_t *)m + (e >> 1);
+        const uint32_t sh = (uint32_t)(e & 1) << 4;
+        uint32_t d[11];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) d[i] = q[i];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const uint32_t x = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh);
+            p[2 * i] = (int)(x & 0xffffu);
+            if (2 * i + 1 < 19) p[2 * i + 1] = (int)(x >> 16);
+        }
     }
-    if (sig * 2 < 3 * noise) return false;
-    if ((int)p[5] >= high || (int)p[6] >= high || (int)p[7] >= high || (int)p[8] >= high || (int)p[14] >= high ||
-        (int)p[15] >= high || (int)p[16] >= high || (int)p[17] >= high || (int)p[18] >= high)
-        return false;
-    return true;
+    const bool l0 = p[0] < p[1], g1 = p[1] > p[2], l2 = p[2] < p[3], g2 = p[2] > p[3], g3 = p[3] > p[4], l3 = p[3] < p[4],
+               g4 = p[4] > p[5], l8 = p[8] < p[9], g9 = p[9] > p[10], l9 = p[9] < p[10], l10 = p[10] < p[11], g10 = p[10] > p[11],
+               l11 = p[11] < p[12], g12 = p[12] > p[13];
+    const bool c1 = g1 & l2 & g3 & l8 & g9 & l10;
+    const bool c2 = g1 & l2 & g3 & l8 & g9 & l11;
+    const bool c3 = g1 & l2 & g4 & l8 & g10 & l11;
+    const bool c4 = g1 & l3 & g4 & l9 & g10 & l11;
+    const bool c5 = g2 & l3 & g4 & l9 & g10 & l11;
+    const int h1 = p[1] + p[3] + p[9] + p[11] + p[12], s1 = p[1] + p[3] + p[9], n1 = p[5] + p[6] + p[7];
+    const int h2 = p[1] + p[3] + p[9] + p[12], s2 = h2, n2 = n1 + p[8];
+    const int h3 = p[1] + p[3] + p[4] + p[9] + p[10] + p[12], s3 = p[1] + p[12], n3 = p[6] + p[7];
+    const int h4 = p[1] + p[4] + p[10] + p[12], s4 = h4, n4 = n2;
+    const int h5 = p[1] + p[2] + p[4] + p[10] + p[12], s5 = p[4] + p[10] + p[12], n5 = p[6] + p[7] + p[8];
+    const int hs = c1 ? h1 : c2 ? h2 : c3 ? h3 : c4 ? h4 : h5;
+    const int sig = c1 ? s1 : c2 ? s2 : c3 ? s3 : c4 ? s4 : s5;
+    const int noise = c1 ? n1 : c2 ? n2 : c3 ? n3 : c4 ? n4 : n5;
+    const int high = hs / 4;
+    const int quiet = max(max(max(p[5], p[6]), max(p[7], p[8])), max(max(max(p[14], p[15]), max(p[16], p[17])), p[18]));
+    return l0 & g12 & (c1 | c2 | c3 | c4 | c5) & (sig * 2 >= 3 * noise) & (quiet < high);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -113,6 +118,32 @@ __device__ __forceinline__ int corr(const uint16_t *m) {
     if constexpr (PH == 2) return 3 * a + b - 4 * c;
     if constexpr (PH == 3) return 2 * a + 3 * b - 5 * c;
     return a + 5 * b - 5 * c - (int)m[3];
+}
+
+template <int PH>
+__device__ __forceinline__ int corrv(int a, int b, int c, int d) {
+    if constexpr (PH == 0) return 5 * a - 3 * b - 2 * c;
+    if constexpr (PH == 1) return 4 * a - b - 3 * c;
+    if constexpr (PH == 2) return 3 * a + b - 4 * c;
+    if constexpr (PH == 3) return 2 * a + 3 * b - 5 * c;
+    return a + 5 * b - 5 * c - d;
+}
+
+// Correlator PH at sample index e of the (4-byte aligned) magnitude array m, fetched as two or three
+// aligned dwords (one ds_read2_b32, plus one ds_read_b32 for the 4-tap correlator) instead of 3-4
+// 16-bit reads: the LDS pipe charges per instruction, not per byte.
+template <int PH>
+__device__ __forceinline__ int corr_at(const uint16_t *m, int e) {
+    const uint32_t *q = (const uint32_t *)m + (e >> 1);
+    const uint32_t sh = (uint32_t)(e & 1) << 4;
+    const uint32_t d0 = q[0], d1 = q[1];
+    const uint32_t x = __builtin_amdgcn_alignbit(d1, d0, sh);  // samples e, e+1
+    if constexpr (PH < 4) {
+        return corrv<PH>((int)(x & 0xffffu), (int)(x >> 16), (int)((d1 >> sh) & 0xffffu), 0);
+    } else {
+        const uint32_t y = __builtin_amdgcn_alignbit(q[2], d1, sh);  // samples e+2, e+3
+        return corrv<4>((int)(x & 0xffffu), (int)(x >> 16), (int)(y & 0xffffu), (int)(y >> 16));
+    }
 }
 
 __device__ __forceinline__ int slice_corr(const uint16_t *m, int phase) {
@@ -160,27 +191,43 @@ __device__ int slice_phase(const uint16_t *d, int tp, uint32_t w[4]) {
 // The dense slicer: within any 5 consecutive bits every correlator is used exactly once, so a lane
 // can evaluate "correlator 0, 1, 2, 3, 4" in that fixed order -- the same instruction stream for
 // every trial phase -- and only the sample offset and the bit each result lands on differ per lane.
+struct RotTables {
+    uint32_t off[5], bit[5];  // per trial phase 4..8: five nibbles / five 5-bit masks, one per correlator
+};
+constexpr RotTables make_rot_tables() {
+    RotTables t{};
+    for (int tp = 4; tp <= 8; ++tp) {
+        uint32_t o = 0, b = 0;
+        for (int q = 0; q < 5; ++q) {
+            const int j = ((q + 10 - tp) * 3) % 5;  // bit j of the group uses correlator (tp + 2j) % 5 == q
+            o |= (uint32_t)((tp + 12 * j) / 5) << (4 * q);
+            b |= (16u >> j) << (5 * q);
+        }
+        t.off[tp - 4] = o;
+        t.bit[tp - 4] = b;
+    }
+    return t;
+}
+constexpr RotTables kRot = make_rot_tables();
+
 struct RotSlicer {
     int off[5];       // sample offset (relative to the group base) at which correlator q is evaluated
     uint32_t bit[5];  // the bit of the 5-bit group that correlator q decides (MSB = earliest bit)
-    __device__ __forceinline__ explicit RotSlicer(int tp) {
+    __device__ __forceinline__ explicit RotSlicer(uint32_t phase /* try_phase - 4 */) {
+        const uint32_t o = phase == 0 ? kRot.off[0] : phase == 1 ? kRot.off[1] : phase == 2 ? kRot.off[2] : phase == 3 ? kRot.off[3] : kRot.off[4];
+        const uint32_t b = phase == 0 ? kRot.bit[0] : phase == 1 ? kRot.bit[1] : phase == 2 ? kRot.bit[2] : phase == 3 ? kRot.bit[3] : kRot.bit[4];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            const int j = ((q + 10 - tp) * 3) % 5;  // bit j of the group uses correlator (tp + 2j) % 5 == q
-            off[q] = (tp + 12 * j) / 5;
-            bit[q] = 16u >> j;
+            off[q] = (int)((o >> (4 * q)) & 15u);
+            bit[q] = (b >> (5 * q)) & 31u;
         }
     }
-    // five bits starting at bit 5*G of the message; d = &S[g + 19]
-    __device__ __forceinline__ uint32_t group(const uint16_t *d, int G) const {
-        const uint16_t *b = d + 12 * G;
-        uint32_t r = 0;
-        r |= (corr<0>(b + off[0]) > 0) ? bit[0] : 0u;
-        r |= (corr<1>(b + off[1]) > 0) ? bit[1] : 0u;
-        r |= (corr<2>(b + off[2]) > 0) ? bit[2] : 0u;
-        r |= (corr<3>(b + off[3]) > 0) ? bit[3] : 0u;
-        r |= (corr<4>(b + off[4]) > 0) ? bit[4] : 0u;
-        return r;
+    // five bits starting at bit 5*G of the message; m = the strip's magnitudes, e = index of S[g + 19]
+    __device__ __forceinline__ uint32_t group(const uint16_t *m, int e, int G) const {
+        const int b = e + 12 * G;
+        const int c0 = corr_at<0>(m, b + off[0]), c1 = corr_at<1>(m, b + off[1]), c2 = corr_at<2>(m, b + off[2]),
+                  c3 = corr_at<3>(m, b + off[3]), c4 = corr_at<4>(m, b + off[4]);
+        return (c0 > 0 ? bit[0] : 0u) | (c1 > 0 ? bit[1] : 0u) | (c2 > 0 ? bit[2] : 0u) | (c3 > 0 ? bit[3] : 0u) | (c4 > 0 ? bit[4] : 0u);
     }
 };
 
@@ -219,6 +266,11 @@ __device__ __forceinline__ uint32_t repair_aa(uint32_t addr, uint32_t info) {  /
     return addr;
 }
 
+__device__ __forceinline__ void mark_adder(uint32_t *adders, uint32_t addr) {  // mode_s.c:717-726
+    const uint32_t bit = 1u << (addr & 31);
+    if (!(adders[addr >> 5] & bit)) atomicOr(&adders[addr >> 5], bit);
+}
+
 constexpr uint32_t kDeadItem = 0xffffffffu;
 constexpr uint32_t kShortDfMask = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);                          // demod_2400.c:274
 constexpr uint32_t kLongDfMask = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21) | (1u << 24);  // demod_2400.c:278
@@ -241,7 +293,7 @@ __device__ uint32_t classify(const uint32_t w[4], const DeviceTables &t, const u
         }
         const uint32_t addr = repair_aa(aa, info);
         if (iid == 0) {
-            if (s == 0) atomicOr(&adders[addr >> 5], 1u << (addr & 31));  // mode_s.c:717-726
+            if (s == 0) mark_adder(adders, addr);
             return ((kComboDf11Iid0 + (info & 0xff)) << 27) | addr;
         }
         return ((kComboDf11IidX + (info & 0xff)) << 27) | addr;
@@ -254,18 +306,24 @@ __device__ uint32_t classify(const uint32_t w[4], const DeviceTables &t, const u
             if (info == kDeadItem) return kDeadItem;
         }
         const uint32_t addr = repair_aa(aa, info);
-        if (df == 17 && syn == 0) atomicOr(&adders[addr >> 5], 1u << (addr & 31));
+        if (df == 17 && syn == 0) mark_adder(adders, addr);
         const uint32_t e = info & 0xff;
         const uint32_t sub = e ? (2 * e - 1 + (addr != aa)) : 0;
         return (((df == 17 ? kComboDf17 : kComboDf18) + sub) << 27) | addr;
     }
 }
 
-__device__ __forceinline__ void emit_item(const BatchArgs &a, uint32_t g, uint32_t phase, uint32_t cls) {
-    if (cls == kDeadItem) return;
+// Items leave the scan kernel without contended atomics: every wavefront owns a region of the item
+// array (a.items + wave * a.item_region) and counts its items in a register; only the rare
+// per-thread paths share one extra region behind an atomic counter.
+__device__ __forceinline__ void emit_item_shared(const BatchArgs &a, uint32_t g, uint32_t info) {
     const uint32_t slot = atomicAdd(&a.counters[kCntItems], 1u);
-    if (slot < a.item_cap) a.items[slot] = ItemRec{g, cls | (phase << 24)};
+    if (slot < a.shared_cap) a.items[(size_t)a.n_regions * a.item_region + slot] = ItemRec{g, info};
 }
+__device__ __forceinline__ void emit_item(const BatchArgs &a, uint32_t g, uint32_t phase, uint32_t cls) {
+    if (cls != kDeadItem) emit_item_shared(a, g, cls | (phase << 24));
+}
+
 
 // per-thread path for one trial phase (any length); used when an LDS queue is full
 __device__ void slow_item(const BatchArgs &a, const uint16_t *d, uint32_t g, int phase, const uint32_t *crcb) {
@@ -278,25 +336,51 @@ __device__ void slow_item(const BatchArgs &a, const uint16_t *d, uint32_t g, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// the scan kernel
+// the scan kernel: wave-autonomous strips
+//
+// One 1024-thread workgroup per CU shares the 32 KB folded UC8 table; after that each of its 16
+// wavefronts works alone on strips of 2048 scan offsets with its own 7.6 KB of LDS (magnitudes of
+// the strip + 304-sample halo, and three small queues).  A strip goes through all stages inside
+// its wavefront, so no workgroup barrier is ever executed: while one wavefront is in a stage that
+// keeps few lanes busy, the other wavefronts of the SIMD are in other stages.
 
-constexpr int kScanT = 8192;                      // scan offsets per tile
-constexpr int kScanThreads = 512;
-constexpr int kScanVecs = (kScanT + kHalo) / 8;   // 16-byte vectors of 8 magnitudes per tile
-constexpr int kTileShift = 2;   // tiles start at S index t*T - 2: then their first IQ sample, t*T - 328, is a multiple of 8
-constexpr int kEdgeCap = 4096;  // edge-pattern candidates of half a tile (at most 2 of any 3 consecutive offsets can pass)
-constexpr int kGateCap = 768;   // gated offsets per tile that go through the dense stages; more take the per-thread path
-constexpr int kListCap = 1536;  // short / long items per tile in the dense stages
+constexpr int kStrip = 2048;                      // scan offsets per strip
+constexpr int kStripVecs = (kStrip + kHalo) / 8;  // 16-byte vectors of 8 magnitudes per strip (294)
+constexpr int kScanWaves = 16;
+constexpr int kScanThreads = 64 * kScanWaves;
+constexpr int kTileShift = 2;   // strips start at S index k*2048 - 2: then their first IQ sample, k*2048 - 328, is a multiple of 8
+constexpr int kEdgeCap = 704;   // edge-pattern candidates of half a strip (at most 2 of any 3 consecutive offsets can pass)
+constexpr int kGateCap = 192;   // gated offsets per strip that go through the dense stages; more take the per-thread path
+constexpr int kListCap = 320;   // short / long items per strip in the dense stages
 
-struct __attribute__((aligned(16))) ScanShared {
-    uint16_t m[kScanT + kHalo];
-    uint16_t lut[16384];
+struct __attribute__((aligned(16))) WaveShared {
+    uint16_t m[kStrip + kHalo];
     uint16_t eq[kEdgeCap];
     uint16_t gq[kGateCap];
     uint16_t lst[2][kListCap];
-    uint32_t crcb[256];
-    uint32_t cnt[6];  // edge candidates (first half), gated, short items, long items, edge candidates (second half)
 };
+static_assert(sizeof(WaveShared) % 16 == 0, "per-wave LDS regions must keep 16-byte alignment");
+
+struct __attribute__((aligned(16))) ScanShared {
+    uint16_t lut[16384];
+    uint32_t crcb[256];
+    uint32_t gsyn_long[23 * 32];   // per 5-bit group of a 112-bit frame: XOR of the single-bit syndromes of the set bits
+    uint32_t gsyn_short[12 * 32];  // same for 56-bit frames
+    WaveShared w[kScanWaves];
+};
+static_assert(sizeof(ScanShared) <= 160 * 1024, "LDS budget of one CU");
+
+// compiler-level ordering of this wavefront's own LDS traffic (the hardware executes a wave's LDS
+// instructions in order; nothing here is shared with another wavefront)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // set bits of mask in lanes below this one
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
 
 __device__ __forceinline__ uint32_t uc8_pair(uint32_t x, const uint16_t *lut) {
     // two UC8 samples (I0 Q0 I1 Q1) -> two magnitudes. |v - 127.5| - 0.5 per byte, then the folded
@@ -319,10 +403,111 @@ __device__ __forceinline__ uint32_t sc16_pair(uint4 v, int which) {
     return m0 | (m1 << 16);
 }
 
+// Which branch of scoreModesMessage does a sliced frame take (mode_s.c:330-408)?  Works from the
+// pieces the group-parallel slicer reduces: DF + AA (the first 32 bits), the CRC syndrome, and
+// whether any message bit is set.  combo << 27 | value, or kDeadItem.
+template <bool LONG>
+__device__ uint32_t classify_fields(uint32_t w0, uint32_t syn, bool nonzero, const DeviceTables &t, uint32_t *adders) {
+    const uint32_t df = w0 >> 27, aa = w0 & 0xffffffu;
+    if (!LONG) {
+        if (!nonzero) return kDeadItem;                    // all-zero message, mode_s.c:325
+        if (df != 11) return (kComboApShort << 27) | syn;  // DF0/4/5: Address/Parity
+        const uint32_t s = syn & 0xffff80u, iid = syn & 0x7fu;
+        uint32_t info = 0;
+        if (s) {
+            info = diagnose(t, 0, s);
+            if (info == kDeadItem || (info & 0xff) > 1) return kDeadItem;  // mode_s.c:350-358
+        }
+        const uint32_t addr = repair_aa(aa, info);
+        if (iid == 0) {
+            if (s == 0) mark_adder(adders, addr);
+            return ((kComboDf11Iid0 + (info & 0xff)) << 27) | addr;
+        }
+        return ((kComboDf11IidX + (info & 0xff)) << 27) | addr;
+    } else {
+        if (df == 16 || df == 24) return (kComboApLong << 27) | syn;
+        if (df == 20 || df == 21) return (kComboCommB << 27) | syn;  // exact match or nothing (mode_s.c:391-403)
+        uint32_t info = 0;  // DF17/18
+        if (syn) {
+            info = diagnose(t, 1, syn);
+            if (info == kDeadItem) return kDeadItem;
+        }
+        const uint32_t addr = repair_aa(aa, info);
+        if (df == 17 && syn == 0) mark_adder(adders, addr);
+        const uint32_t e = info & 0xff;
+        const uint32_t sub = e ? (2 * e - 1 + (addr != aa)) : 0;
+        return (((df == 17 ? kComboDf17 : kComboDf18) + sub) << 27) | addr;
+    }
+}
+
+// butterfly reductions inside 8 / 16 consecutive lanes with DPP moves (no LDS traffic)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int SEG, typename OP>
+__device__ __forceinline__ uint32_t seg_reduce(uint32_t v, OP op) {
+    v = op(v, dpp_mov<0xB1>(v));                 // quad_perm [1,0,3,2]
+    v = op(v, dpp_mov<0x4E>(v));                 // quad_perm [2,3,0,1]
+    v = op(v, dpp_mov<0x141>(v));                // row_half_mirror: lane i <-> 7-i of each 8
+    if (SEG == 16) v = op(v, dpp_mov<0x140>(v)); // row_mirror: lane i <-> 15-i of each 16
+    return v;
+}
+
+// Group-parallel slicing of one frame by SEG lanes (8 for 56-bit frames, 16 for 112-bit frames):
+// lane `sub` of the segment slices groups sub and sub + 12 (sub + 6 for short frames), five bits each, and looks up the XOR of
+// the syndromes of their set bits (the CRC is linear: crc.c:59-64,140; one 32-entry table per group);
+// the segment then reduces syndrome, first message word and a non-zero flag.  Straight-line code:
+// out-of-range groups are clamped and masked instead of branched around.
+template <bool LONG>
+__device__ __forceinline__ void slice_segment(const BatchArgs &a, const ScanShared &sh, const uint16_t *m, int e, uint32_t g, uint32_t phase,
+                                              uint32_t sub, bool valid, ItemRec *region, uint32_t &nitems) {
+    constexpr int kGroups = LONG ? 23 : 12, kSeg = LONG ? 16 : 8;
+    const uint32_t *gsyn = LONG ? sh.gsyn_long : sh.gsyn_short;
+    const RotSlicer rs(phase);
+    // lane sub slices groups sub and sub + SEG*3/4: neighbouring lanes then read LDS 24 bytes apart
+    // (distinct banks) instead of 48
+    constexpr int kHalf = LONG ? 12 : 6;
+    const int G0 = (int)sub, G1 = G0 + kHalf;
+    const bool v0 = valid && G0 < kHalf, v1 = valid && G0 < kHalf && G1 < kGroups;
+    const int H0 = v0 ? G0 : 0, H1 = v1 ? G1 : 0;
+    uint32_t b0 = 21, b1 = 10;
+    if (!(a.debug_flags & 2)) {
+        b0 = rs.group(m, e, H0);
+        b1 = rs.group(m, e, H1);
+    }
+    if (!LONG) {  // groups 11 holds bits 55..59: only bit 55 belongs to the frame
+        b1 = (H1 == 11) ? (b1 & 16u) : b1;
+    } else {      // group 22 holds bits 110..114: only 110 and 111 belong to the frame
+        b1 = (H1 == 22) ? (b1 & 24u) : b1;
+    }
+    b0 = v0 ? b0 : 0u;
+    b1 = v1 ? b1 : 0u;
+    uint32_t syn = gsyn[H0 * 32 + b0] ^ gsyn[H1 * 32 + b1];  // entry 0 of every group is 0
+    // groups 0..6 make up message bits 0..34; keep the first 32 (DF + AA)
+    const uint64_t top = (H0 <= 6 ? ((uint64_t)b0 << (59 - 5 * H0)) : 0ull) | (H1 <= 6 ? ((uint64_t)b1 << (59 - 5 * H1)) : 0ull);
+    uint32_t w0 = (uint32_t)(top >> 32);
+    uint32_t nz = b0 | b1;
+    if (!(a.debug_flags & 4)) {
+        syn = seg_reduce<kSeg>(syn, [](uint32_t x, uint32_t y) { return x ^ y; });
+        w0 = seg_reduce<kSeg>(w0, [](uint32_t x, uint32_t y) { return x | y; });
+        nz = seg_reduce<kSeg>(nz, [](uint32_t x, uint32_t y) { return x | y; });
+    }
+    uint32_t cls = kDeadItem;
+    if (valid && sub == 0 && !(a.debug_flags & 1)) cls = classify_fields<LONG>(w0, syn, nz != 0, a.tab, a.adder_bitmap);
+    const uint64_t em = __ballot(cls != kDeadItem);
+    if (cls != kDeadItem) {
+        const uint32_t pos = nitems + lanes_below(em);
+        if (pos < a.item_region) region[pos] = ItemRec{g, cls | (phase << 24)};
+    }
+    nitems += __popcll(em);
+}
+
 template <int FMT>
 __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
-    __shared__ ScanShared sh;
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
+    ScanShared &sh = *reinterpret_cast<ScanShared *>(scan_lds);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     if (FMT == kFmtUC8)
         for (uint32_t i = tid; i < 16384; i += kScanThreads) {
@@ -330,15 +515,30 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             sh.lut[i ^ ((aq & 31) << 1)] = a.tab.uc8_lut[((128 + aq) << 8) | (128 + ai)];
         }
     if (tid < 256) sh.crcb[tid] = a.tab.crc_bytes[tid];
+    for (uint32_t i = tid; i < 23 * 32 + 12 * 32; i += kScanThreads) {
+        // crc.c:59-64: bit k of an n-bit frame has the syndrome of bit k + 112 - n of a 112-bit frame
+        const bool lng = i < 23 * 32;
+        const uint32_t e = lng ? i : i - 23 * 32, G = e >> 5, v = e & 31, nbits = lng ? 112 : 56;
+        uint32_t x = 0;
+        for (uint32_t j = 0; j < 5; ++j) {
+            const uint32_t k = 5 * G + j;
+            if (((v >> (4 - j)) & 1) && k < nbits) x ^= a.tab.sbs[k + 112 - nbits];
+        }
+        (lng ? sh.gsyn_long : sh.gsyn_short)[e] = x;
+    }
+    __syncthreads();  // the only workgroup barrier
 
-    const uint64_t ntiles = (a.n + kTileShift + kScanT - 1) / kScanT;
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int64_t s0 = (int64_t)(t * kScanT) - kTileShift;  // S index of m[0]
-        __syncthreads();  // previous tile fully consumed; LUT ready
-        if (tid < 6) sh.cnt[tid] = 0;
+    WaveShared &W = sh.w[wave];
+    const uint32_t gwave = blockIdx.x * kScanWaves + wave;
+    ItemRec *region = a.items + (size_t)gwave * a.item_region;
+    uint32_t nitems = 0, gated_total = 0, slow_total = 0;  // wave-uniform
+    const uint64_t nstrips = (a.n + kTileShift + kStrip - 1) / kStrip;
+    for (uint64_t strip = (uint64_t)blockIdx.x * kScanWaves + wave; strip < nstrips; strip += (uint64_t)gridDim.x * kScanWaves) {
+        const int64_t s0 = (int64_t)(strip * kStrip) - kTileShift;  // S index of m[0]
+        wave_sync();
 
-        // ---- convert.c: tile + halo -> magnitudes in LDS
-        for (int v = tid; v < kScanVecs; v += kScanThreads) {
+        // ---- convert.c: strip + halo -> magnitudes in LDS
+        for (int v = lane; v < kStripVecs; v += 64) {
             const int64_t s = s0 + 8 * v, q = s - (int64_t)kTrailing;
             uint4 o;
             if ((FMT == kFmtUC8) && a.iq_aligned && q >= 0 && q + 8 <= (int64_t)a.n) {
@@ -354,16 +554,19 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 for (int k = 0; k < 8; ++k) e[k] = stream_mag<FMT>(a, s + k);
                 o = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
             }
-            ((uint4 *)sh.m)[v] = o;
+            ((uint4 *)W.m)[v] = o;
         }
-        __syncthreads();
+        wave_sync();
+        if (a.stage_limit < 2) continue;
 
+        uint32_t ngated = 0;  // wave-uniform
         for (int h = 0; h < 2; ++h) {
             // ---- demod_2400.c:109-155, edge patterns only, 64 lanes x 8 consecutive offsets per ballot
-            {
-                const int base = h * (kScanT / 2) + (int)tid * 8;
+            uint32_t neq = 0;
+            for (int r = 0; r < 2; ++r) {
+                const int base = (h * 2 + r) * 512 + (int)lane * 8;
                 uint32_t w[22];
-                const uint4 *src = (const uint4 *)&sh.m[base];
+                const uint4 *src = (const uint4 *)&W.m[base];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const uint4 v = src[q];
@@ -380,8 +583,6 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                     L[j] = __ballot(w[j] < w[j + 1]);
                     G[j] = __ballot(w[j] > w[j + 1]);
                 }
-                uint64_t E[8];
-                uint32_t total = 0;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const uint64_t *l = &L[k], *g = &G[k];
@@ -389,121 +590,148 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                     const uint64_t A = g[1] & l[2], B = l[3] & g[4], C = l[8] & g[9], D = g[10] & l[11];
                     const uint64_t p12 = A & g[3] & C & (l[10] | l[11]);
                     const uint64_t p345 = ((A & g[4] & l[8]) | (B & l[9] & (g[1] | g[2]))) & D;
-                    E[k] = (p12 | p345) & l[0] & g[12];
-                    total += __popcll(E[k]);
-                }
-                if (total) {
-                    uint32_t wbase = 0;
-                    if (lane == 0) wbase = atomicAdd(&sh.cnt[4 * h], total);
-                    wbase = __builtin_amdgcn_readfirstlane(wbase);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if ((E[k] >> lane) & 1) {
-                            const uint32_t pos = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(E[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E[k], 0));
-                            if (pos < (uint32_t)kEdgeCap) sh.eq[pos] = (uint16_t)(base + k);
-                        }
-                        wbase += __popcll(E[k]);
+                    const uint64_t E = (p12 | p345) & l[0] & g[12];
+                    if ((E >> lane) & 1) {
+                        const uint32_t pos = neq + lanes_below(E);
+                        if (pos < (uint32_t)kEdgeCap) W.eq[pos] = (uint16_t)(base + k);
                     }
+                    neq += __popcll(E);
                 }
             }
-            __syncthreads();
+            wave_sync();
+            if (a.stage_limit < 3) continue;
 
             // ---- the whole gate (:109-172) on the edge candidates; survivors go to the gated queue
-            {
-                const uint32_t neq = min(sh.cnt[4 * h], (uint32_t)kEdgeCap);
-                for (uint32_t c = tid; c < neq; c += kScanThreads) {
-                    const uint32_t j = sh.eq[c];
+            neq = min(neq, (uint32_t)kEdgeCap);
+            for (uint32_t cb = 0; cb < neq; cb += 64) {
+                const uint32_t c = cb + lane;
+                uint32_t j = 0;
+                bool pass = false;
+                if (c < neq) {
+                    j = W.eq[c];
                     const int64_t g = s0 + j;
-                    if (g < 0 || (uint64_t)g >= a.n) continue;
-                    if (!preamble_gate(&sh.m[j])) continue;
+                    pass = g >= 0 && (uint64_t)g < a.n && preamble_gate(W.m, (int)j);
+                }
+                const uint64_t pm = __ballot(pass);
+                if (pass) {
+                    const uint32_t g = (uint32_t)(s0 + j);
+                    const uint32_t pos = ngated + lanes_below(pm);
                     if (a.emit_dead) {
-                        const uint32_t slot = atomicAdd(&a.counters[kCntItems], 1u);
-                        if (slot < a.item_cap) a.items[slot] = ItemRec{(uint32_t)g, (kComboMarker << 27) | (7u << 24)};
+                        const uint32_t ipos = nitems + lanes_below(pm);
+                        if (ipos < a.item_region) region[ipos] = ItemRec{g, (kComboMarker << 27) | (7u << 24)};
                     }
-                    const uint32_t pos = atomicAdd(&sh.cnt[1], 1u);
                     if (pos < (uint32_t)kGateCap) {
-                        sh.gq[pos] = (uint16_t)j;
+                        W.gq[pos] = (uint16_t)j;
                     } else {
-                        atomicAdd(&a.counters[kCntSlowPath], 1u);
-                        for (int p = 0; p < 5; ++p) slow_item(a, &sh.m[j + 19], (uint32_t)g, p, sh.crcb);
+                        for (int p = 0; p < 5; ++p) slow_item(a, &W.m[j + 19], g, p, sh.crcb);
                     }
                 }
+                if (a.emit_dead) nitems += __popcll(pm);
+                ngated += __popcll(pm);
             }
-            __syncthreads();
+            wave_sync();
         }
-
-        const uint32_t ngated = sh.cnt[1];
+        gated_total += ngated;
+        if (ngated > (uint32_t)kGateCap) slow_total += ngated - kGateCap;
+        if (a.stage_limit < 4) continue;
         const uint32_t ngq = min(ngated, (uint32_t)kGateCap);
-        if (tid == 0 && ngated) atomicAdd(&a.counters[kCntGated], ngated);
 
         // ---- first five bits (the DF) of every (offset, trial phase): which length class? (:272-285)
-        for (uint32_t i = tid; i < 5 * ngq; i += kScanThreads) {
-            const uint32_t cand = i / 5, phase = i - 5 * cand;
-            const uint32_t j = sh.gq[cand];
-            const RotSlicer rs((int)phase + 4);
-            const uint32_t df = rs.group(&sh.m[j + 19], 0);
-            const uint32_t cls = ((kShortDfMask >> df) & 1) ? 0u : (((kLongDfMask >> df) & 1) ? 1u : 2u);
-            if (cls < 2) {
-                const uint32_t pos = atomicAdd(&sh.cnt[2 + cls], 1u);
-                if (pos < (uint32_t)kListCap) {
-                    sh.lst[cls][pos] = (uint16_t)i;
-                } else {
-                    atomicAdd(&a.counters[kCntSlowPath], 1u);
-                    slow_item(a, &sh.m[j + 19], (uint32_t)(s0 + j), (int)phase, sh.crcb);
+        uint32_t nlist[2] = {0, 0};
+        for (uint32_t ib = 0; ib < 5 * ngq; ib += 64) {
+            const uint32_t i = ib + lane;
+            uint32_t cls = 2, j = 0, phase = 0;
+            if (i < 5 * ngq) {
+                const uint32_t cand = i / 5;
+                phase = i - 5 * cand;
+                j = W.gq[cand];
+                const RotSlicer rs(phase);
+                const uint32_t df = rs.group(W.m, (int)j + 19, 0);
+                cls = ((kShortDfMask >> df) & 1) ? 0u : (((kLongDfMask >> df) & 1) ? 1u : 2u);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 2; ++k) {
+                const uint64_t cm = __ballot(cls == k);
+                if (cls == k) {
+                    const uint32_t pos = nlist[k] + lanes_below(cm);
+                    if (pos < (uint32_t)kListCap) {
+                        W.lst[k][pos] = (uint16_t)i;
+                    } else {
+                        slow_item(a, &W.m[j + 19], (uint32_t)(s0 + j), (int)phase, sh.crcb);
+                    }
                 }
+                nlist[k] += __popcll(cm);
             }
         }
-        __syncthreads();
-        const uint32_t ns = min(sh.cnt[2], (uint32_t)kListCap), nl = min(sh.cnt[3], (uint32_t)kListCap);
+        if (nlist[0] > (uint32_t)kListCap) slow_total += nlist[0] - kListCap;
+        if (nlist[1] > (uint32_t)kListCap) slow_total += nlist[1] - kListCap;
+        wave_sync();
+        if (a.stage_limit < 5) continue;
 
-        // ---- 56-bit frames: 12 groups of 5 bits
+        // ---- 56-bit frames: eight lanes per frame
         {
-            for (uint32_t c = tid; c < ns; c += kScanThreads) {
-                const uint32_t i = sh.lst[0][c], cand = i / 5, phase = i - 5 * cand;
-                const uint32_t j = sh.gq[cand];
-                const RotSlicer rs((int)phase + 4);
-                const uint16_t *d = &sh.m[j + 19];
-                uint64_t acc = 0;
-#pragma unroll
-                for (int G = 0; G < 12; ++G) acc = (acc << 5) | rs.group(d, G);
-                acc <<= 4;  // message bit 0 -> bit 63; bits 7..4 hold the four extra bits sliced
-                uint32_t w[4] = {(uint32_t)(acc >> 32), (uint32_t)acc & 0xffffff00u, 0, 0};
-                emit_item(a, (uint32_t)(s0 + j), phase, classify<7>(w, a.tab, sh.crcb, a.adder_bitmap));
+            const uint32_t ns = min(nlist[0], (uint32_t)kListCap);
+            for (uint32_t cb = 0; cb < ns; cb += 8) {
+                const uint32_t c = cb + (lane >> 3);
+                const bool valid = c < ns;
+                uint32_t j = 0, phase = 0;
+                if (valid) {
+                    const uint32_t i = W.lst[0][c], cand = i / 5;
+                    phase = i - 5 * cand;
+                    j = W.gq[cand];
+                }
+                slice_segment<false>(a, sh, W.m, (int)j + 19, (uint32_t)(s0 + j), phase, lane & 7, valid, region, nitems);
             }
         }
-        // ---- 112-bit frames: 23 groups of 5 bits
+        if (a.stage_limit < 6) continue;
+        // ---- 112-bit frames: sixteen lanes per frame
         {
-            for (uint32_t c = tid; c < nl; c += kScanThreads) {
-                const uint32_t i = sh.lst[1][c], cand = i / 5, phase = i - 5 * cand;
-                const uint32_t j = sh.gq[cand];
-                const RotSlicer rs((int)phase + 4);
-                const uint16_t *d = &sh.m[j + 19];
-                uint64_t hi = 0, lo = 0;  // 128-bit shift register
-#pragma unroll
-                for (int G = 0; G < 23; ++G) {
-                    hi = (hi << 5) | (lo >> 59);
-                    lo = (lo << 5) | rs.group(d, G);
+            const uint32_t nl = min(nlist[1], (uint32_t)kListCap);
+            for (uint32_t cb = 0; cb < nl; cb += 4) {
+                const uint32_t c = cb + (lane >> 4);
+                const bool valid = c < nl;
+                uint32_t j = 0, phase = 0;
+                if (valid) {
+                    const uint32_t i = W.lst[1][c], cand = i / 5;
+                    phase = i - 5 * cand;
+                    j = W.gq[cand];
                 }
-                hi = (hi << 13) | (lo >> 51);  // message bit 0 -> bit 127; bits 15..13 hold the three extra bits
-                lo <<= 13;
-                uint32_t w[4] = {(uint32_t)(hi >> 32), (uint32_t)hi, (uint32_t)(lo >> 32), (uint32_t)lo & 0xffff0000u};
-                emit_item(a, (uint32_t)(s0 + j), phase, classify<14>(w, a.tab, sh.crcb, a.adder_bitmap));
+                slice_segment<true>(a, sh, W.m, (int)j + 19, (uint32_t)(s0 + j), phase, lane & 15, valid, region, nitems);
             }
         }
     }
+    if (lane == 0) {
+        a.region_counts[gwave] = nitems;
+        if (gated_total) atomicAdd(&a.counters[kCntGated], gated_total);
+        if (slow_total) atomicAdd(&a.counters[kCntSlowPath], slow_total);
+    }
 }
 
+// one workgroup per item region (n_regions wave regions + the shared region)
 __global__ __launch_bounds__(kThreads) void k_prune(const BatchArgs a) {
-    uint32_t n = a.counters[kCntItems];
-    if (n > a.item_cap) n = a.item_cap;
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
-        const ItemRec rec = a.items[i];
+    const uint32_t r = blockIdx.x;
+    uint32_t n, cap;
+    if (r < a.n_regions) {
+        n = a.region_counts[r];
+        cap = a.item_region;
+    } else {
+        n = a.counters[kCntItems];
+        cap = a.shared_cap;
+    }
+    if (n > cap) {
+        if (threadIdx.x == 0) atomicAdd(&a.counters[kCntOverflow], 1u);
+        n = cap;
+    }
+    if (threadIdx.x == 0 && n) atomicAdd(&a.counters[kCntItemsTotal], n);
+    const ItemRec *items = a.items + (size_t)r * a.item_region;
+    for (uint32_t i = threadIdx.x; i < n; i += kThreads) {
+        const ItemRec rec = items[i];
         const uint32_t combo = item_combo(rec.info), v = item_value(rec.info);
         bool keep = a.keep_all != 0 || combo == kComboMarker || !combo_needs_member(combo);
         if (!keep) keep = (a.adder_bitmap[v >> 5] >> (v & 31)) & 1u;
         if (keep) {
             const uint32_t slot = atomicAdd(&a.counters[kCntSurvItems], 1u);
-            if (slot < a.item_cap) {
+            if (slot < a.surv_item_cap) {
                 a.skeys[0][slot] = ((uint64_t)rec.g << 3) | item_phase(rec.info);
                 a.sinfo[0][slot] = rec.info;
             }
@@ -711,23 +939,27 @@ inline unsigned tiles_of(uint64_t n) { return (unsigned)((n + kTile - 1) / kTile
 
 int scan_grid_size(int device) {
     hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 512;
-    return 2 * p.multiProcessorCount;  // two 512-thread workgroups (~64 KB of LDS each) per CU
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 256;
+    return p.multiProcessorCount;  // one 1024-thread workgroup (~158 KB of LDS) per CU
 }
 
 hipError_t launch_scan(const BatchArgs &a, int grid, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    const uint64_t ntiles = (a.n + kTileShift + kScanT - 1) / kScanT;
-    if ((uint64_t)grid > ntiles) grid = (int)ntiles;
+    const uint64_t nstrips = (a.n + kTileShift + kStrip - 1) / kStrip;
+    const uint64_t need = (nstrips + kScanWaves - 1) / kScanWaves;
+    if ((uint64_t)grid > need) grid = (int)need;
     return by_format(a.fmt, [&](auto F) {
-        hipLaunchKernelGGL(k_scan<decltype(F)::value>, dim3(grid), dim3(kScanThreads), 0, s, a);
+        auto kern = k_scan<decltype(F)::value>;
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanShared));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanThreads), sizeof(ScanShared), s, a);
         return hipGetLastError();
     });
 }
 
 hipError_t launch_prune(const BatchArgs &a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_prune, dim3(1024), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL(k_prune, dim3(a.n_regions + 1), dim3(kThreads), 0, s, a);
     return hipGetLastError();
 }
 

@@ -20,12 +20,15 @@ enum : int {
     kCntGated,         // offsets that passed the preamble gate
     kCntSurvivors,     // distinct offsets among the kept items (written by the unique step)
     kCntSlowPath,      // candidates / items that overflowed an LDS queue and took the per-thread path
+    kCntOverflow,      // item regions that overflowed (results incomplete -> RSB_EOVERFLOW)
+    kCntItemsTotal,    // all items (sum over regions), for statistics
     kCntCount = 8
 };
 
 struct DeviceTables {      // read-only, built once per context
     const uint16_t *uc8_lut;       // 65536 x u16
     const uint32_t *crc_bytes;     // 256 x u32
+    const uint32_t *sbs;           // 112 x u32: syndrome of each single set bit of a 112-bit frame (crc.c:40)
     const uint32_t *syn_keys[2];   // [0] = 56-bit frames, [1] = 112-bit frames
     const uint32_t *syn_vals[2];
     uint32_t syn_mask[2];
@@ -41,8 +44,12 @@ struct BatchArgs {
     int iq_aligned;        // iq is 16-byte aligned: the scan kernel may use vector loads
     uint64_t n;
     DeviceTables tab;
-    ItemRec *items;
-    uint32_t item_cap;
+    ItemRec *items;          // n_regions wave-private regions of item_region records, then one shared region
+    uint32_t item_region;
+    uint32_t n_regions;
+    uint32_t shared_cap;
+    uint32_t *region_counts; // items written per wave region
+    uint32_t surv_item_cap;
     uint64_t *skeys[2];    // kept items: sort key g << 3 | phase (ping-pong buffers for the radix sort)
     uint32_t *sinfo[2];    // ... and their info words
     uint32_t *surv_g;      // distinct offsets of the kept items, ascending
@@ -55,6 +62,8 @@ struct BatchArgs {
     uint64_t *block_sums;    // per 131072-block: sum(mag), sum(mag^2) over its new samples
     int emit_dead;           // also emit a marker item per gated offset (exact demod statistics)
     int keep_all;            // prune keeps every item (filter owned by the caller)
+    int debug_flags;         // ablation only (RSB_ABL): 1 skip classify, 2 skip slicing loads, 4 skip reductions
+    int stage_limit;         // debug/ablation only (RSB_STAGE_LIMIT): stop the scan kernel after stage k
 };
 
 int scan_grid_size(int device);
