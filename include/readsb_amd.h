@@ -56,7 +56,14 @@ typedef struct rsb_config {
     int32_t device;            /* HIP device ordinal */
     uint32_t queue_div;        /* device queues hold max_batch_samples/queue_div candidates (0 -> 32) */
     uint64_t max_batch_samples;/* largest nsamples a single rsb_submit will be given */
+    uint32_t flags;            /* RSB_FLAG_* */
+    uint32_t reserved;
 } rsb_config;
+
+/* Run the sequential half (best phase, decode, greedy skip, filter updates) on the host from the
+ * candidate records instead of on the device.  Same results; kept as the cross-check and as the
+ * path a batch falls back to when the ICAO filter is close to full (icao_filter.c:76-79). */
+#define RSB_FLAG_HOST_REPLAY 1u
 
 /* One decoded message: the fields of struct modesMessage (readsb.h:421-439) that the hot path
  * itself produces.  Packed, 56 bytes. */
@@ -77,7 +84,8 @@ typedef struct rsb_message {
 #pragma pack(pop)
 
 /* Counters.  The demod_* members of struct stats (stats.h:62-71) are only exact when the context
- * was created with RSB_FLAG_EXACT_STATS; messages/accepted[] are always exact. */
+ * runs in an exact-statistics mode (not implemented yet: they stay 0); accepted[] / modeac are
+ * always exact. */
 typedef struct rsb_stats {
     uint64_t samples_processed;
     uint64_t demod_preambles, demod_rejected_bad, demod_rejected_unknown_icao;
@@ -95,7 +103,12 @@ typedef struct rsb_timing {
     float prune_ms;     /* filter-superset prune + survivor re-slice */
     float modeac_ms;    /* block statistics + Mode A/C kernel (0 if mode_ac off) */
     float total_ms;     /* first kernel start to last kernel end */
-    float replay_ms;    /* host: sort + sequential replay of the last rsb_collect */
+    float replay_ms;    /* host: sequential replay / filter bookkeeping / Mode A/C merge of the last rsb_collect */
+    float sort_ms;      /* radix sort of the kept items */
+    float device_replay_ms; /* device replay: fixed-point iterations + message emission (0 on the host path) */
+    float copy_ms;      /* device -> host copy of the results */
+    int32_t replay_iterations; /* fixed-point iterations of the device replay (0 on the host path) */
+    int32_t replay_on_device;  /* 1 if the last batch was replayed on the device */
 } rsb_timing;
 
 typedef struct rsb_ctx rsb_ctx;
@@ -123,9 +136,9 @@ int rsb_filter_expire(rsb_ctx *ctx);
  * until rsb_collect returns. */
 int rsb_submit(rsb_ctx *ctx, const void *iq_dev, uint64_t nsamples, void *stream);
 
-/* Wait for the submitted batch, replay the surviving candidates through the reference's
- * sequential rules on the host and append the decoded messages, in the reference's emission
- * order, to out[0..cap).  *n_out receives the number of messages of this batch (if it exceeds
+/* Wait for the submitted batch, run the surviving candidates through the reference's sequential
+ * rules (on the device; on the host with RSB_FLAG_HOST_REPLAY) and store the decoded messages, in
+ * the reference's emission order, to out[0..cap).  `out` may be pinned host memory (faster copy).  *n_out receives the number of messages of this batch (if it exceeds
  * cap only the first cap are stored and RSB_EOVERFLOW is returned). */
 int rsb_collect(rsb_ctx *ctx, rsb_message *out, size_t cap, size_t *n_out);
 

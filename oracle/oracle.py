@@ -92,14 +92,16 @@ class Oracle:
     def reset(self):
         self.lib.orc_reset(self.h)
 
-    def run_stream(self, iq: np.ndarray):
-        """-> (messages as REC_DTYPE array, stats dict)"""
+    def run_stream(self, iq: np.ndarray, reset: bool = True):
+        """-> (messages as REC_DTYPE array, stats dict).  reset=False keeps the ICAO filter as it is
+        (addresses added with filter_add, or learned by an earlier run)."""
         raw = iq_bytes(iq)
         n = raw.size // self.bps
-        cap = max(1024, n // 100)
+        cap = max(1024, n // 100) if reset else max(4096, n // 20)
         while True:
             out = np.zeros(cap, dtype=REC_DTYPE)
-            self.reset()
+            if reset:
+                self.reset()
             got = self.lib.orc_run_stream(self.h, raw.ctypes.data, n, out.ctypes.data, cap)
             if got <= cap:
                 break

@@ -33,7 +33,11 @@ assert MSG_DTYPE.itemsize == 56 and CAND_DTYPE.itemsize == 96 and AC_DTYPE.items
 
 class Config(C.Structure):
     _fields_ = [("input_format", C.c_int32), ("dc_filter", C.c_int32), ("fix_bits", C.c_int32), ("mode_ac", C.c_int32),
-                ("device", C.c_int32), ("queue_div", C.c_uint32), ("max_batch_samples", C.c_uint64)]
+                ("device", C.c_int32), ("queue_div", C.c_uint32), ("max_batch_samples", C.c_uint64),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+FLAG_HOST_REPLAY = 1
 
 
 class Stats(C.Structure):
@@ -45,7 +49,8 @@ class Stats(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("scan_ms", C.c_float), ("prune_ms", C.c_float), ("modeac_ms", C.c_float), ("total_ms", C.c_float),
-                ("replay_ms", C.c_float)]
+                ("replay_ms", C.c_float), ("sort_ms", C.c_float), ("device_replay_ms", C.c_float), ("copy_ms", C.c_float),
+                ("replay_iterations", C.c_int32), ("replay_on_device", C.c_int32)]
 
 
 # every symbol include/readsb_amd.h declares: name -> (restype, argtypes)
@@ -99,11 +104,13 @@ class RsbError(RuntimeError):
 class Channel:
     """One receiver channel (rsb_ctx)."""
 
-    def __init__(self, fmt="UC8", fix_bits=1, mode_ac=False, dc_filter=False, device=0, max_batch_samples=1 << 24, queue_div=0):
+    def __init__(self, fmt="UC8", fix_bits=1, mode_ac=False, dc_filter=False, device=0, max_batch_samples=1 << 24, queue_div=0,
+                 host_replay=False):
         self.l = lib()
         self.fmt = fmt
         self.bps = 2 if fmt == "UC8" else 4
-        cfg = Config(FORMATS[fmt], int(dc_filter), int(fix_bits), int(mode_ac), int(device), int(queue_div), int(max_batch_samples))
+        cfg = Config(FORMATS[fmt], int(dc_filter), int(fix_bits), int(mode_ac), int(device), int(queue_div), int(max_batch_samples),
+                     FLAG_HOST_REPLAY if host_replay else 0, 0)
         h = _VP()
         rc = self.l.rsb_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -127,6 +134,9 @@ class Channel:
 
     def filter_add(self, addr):
         self._check(self.l.rsb_filter_add(self.h, addr), "rsb_filter_add")
+
+    def filter_expire(self):
+        self._check(self.l.rsb_filter_expire(self.h), "rsb_filter_expire")
 
     def submit(self, dev_ptr: int, nsamples: int, stream: int = 0):
         self._check(self.l.rsb_submit(self.h, dev_ptr, nsamples, stream), "rsb_submit")

@@ -1,6 +1,7 @@
 // capi.cpp -- the C ABI of include/readsb_amd.h over the HIP kernels and the host replay.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -93,6 +94,15 @@ int setup_device(rsb_ctx *c) {
     HIP_TRY(c, hipMalloc((void **)&c->d_counters, kCntCount * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_block_sums, c->nblocks_cap * 2 * sizeof(uint64_t)));
     HIP_TRY(c, hipMalloc(&c->d_carry, kTrailing * 4));
+    c->host_replay_only = (c->cfg.flags & RSB_FLAG_HOST_REPLAY) != 0;
+    if (!c->host_replay_only) {
+        for (int w = 0; w < 2; ++w) HIP_TRY(c, hipMalloc((void **)&c->d_first_add[w], sizeof(uint32_t) << 24));
+        HIP_TRY(c, hipMalloc((void **)&c->d_blk_counts, c->nblocks_cap * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_new_adders, rsb_ctx::kNewAddersCap * sizeof(uint2)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_addr_upload, 2 * IcaoFilter::kSlots * sizeof(uint32_t)));
+        // the message records of the device replay reuse the candidate records' memory (one path runs per batch)
+        c->out_cap = (uint32_t)((size_t)c->surv_cap * sizeof(Survivor) / sizeof(rsb_message));
+    }
     for (hipEvent_t &ev : c->ev) HIP_TRY(c, hipEventCreate(&ev));
     return RSB_OK;
 }
@@ -103,7 +113,87 @@ int reset_device(rsb_ctx *c) {
     // icaoFilterTest(0) is true on an empty slot (icao_filter.c:101-107): address 0 is always a "member"
     const uint32_t one = 1;
     HIP_TRY(c, hipMemcpy(c->d_bitmap, &one, sizeof(one), hipMemcpyHostToDevice));
+    c->filter_dirty = true;
     return RSB_OK;
+}
+
+// first-add tables := the host filter's contents (both generations, icao_filter.c:97-119)
+int mirror_filter(rsb_ctx *c, hipStream_t s) {
+    c->replay.filter().contents(c->h_addrs);
+    const uint32_t n = (uint32_t)c->h_addrs.size();
+    if (n) HIP_TRY(c, hipMemcpyAsync(c->d_addr_upload, c->h_addrs.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, launch_filter_rebuild(c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, n, s));
+    HIP_TRY(c, hipStreamSynchronize(s));  // h_addrs is pageable
+    c->first_cur = 0;
+    c->filter_dirty = false;
+    return RSB_OK;
+}
+
+constexpr int kMaxReplayIterations = 16;
+
+// Returns 1 when the batch was replayed on the device (messages in c->d_surv as rsb_message records,
+// counters in cnt), 0 when the host path has to take it, < 0 on error.
+int device_replay(rsb_ctx *c, uint32_t n_items, hipStream_t s, uint32_t cnt[kCntCount]) {
+    const BatchArgs &a = c->pending_args;
+    int rc;
+    if (c->filter_dirty && (rc = mirror_filter(c, s)) != RSB_OK) return rc;
+    ReplayArgs r;
+    std::memset(&r, 0, sizeof(r));
+    r.keys = a.skeys[c->sorted_buf];
+    r.info = a.sinfo[c->sorted_buf];
+    r.n_items = n_items;
+    r.tval = a.surv_g;
+    r.acc = a.sinfo[c->sorted_buf ^ 1];
+    r.acc_idx = (uint32_t *)a.skeys[c->sorted_buf ^ 1];
+    r.blk_counts = c->d_blk_counts;
+    r.nblocks = (uint32_t)((c->pending_n + kBlock - 1) / kBlock);
+    r.new_adders = c->d_new_adders;
+    r.new_adders_cap = rsb_ctx::kNewAddersCap;
+    r.out = (rsb_message *)c->d_surv;
+    r.out_cap = c->out_cap;
+    r.g0 = c->stream_pos;
+    c->timing.replay_iterations = 0;
+    std::memset(cnt + kCntChanged, 0, (kCntCount - kCntChanged) * sizeof(uint32_t));
+    if (r.nblocks == 0) return 1;
+    bool converged = false;
+    for (int it = 0; it < kMaxReplayIterations && !converged; ++it) {
+        r.t_cur = c->d_first_add[c->first_cur];
+        r.t_next = c->d_first_add[c->first_cur ^ 1];
+        HIP_TRY(c, launch_replay_iteration(a, r, s));
+        uint32_t changed = 0;
+        HIP_TRY(c, hipMemcpyAsync(&changed, c->d_counters + kCntChanged, sizeof(changed), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        ++c->timing.replay_iterations;
+        if (!changed) {
+            converged = true;
+        } else {
+            // the table this walk produced becomes the current one; the other goes back to "before this batch"
+            c->first_cur ^= 1;
+            HIP_TRY(c, launch_replay_reset(a, r, c->d_first_add[c->first_cur ^ 1], s));
+        }
+    }
+    if (!converged) {
+        c->filter_dirty = true;
+        return 0;
+    }
+    HIP_TRY(c, launch_replay_finish(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
+    HIP_TRY(c, hipMemcpyAsync(cnt, c->d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_blk_counts.data(), c->d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    // The tables answer "is this address in the filter" as a set.  The reference's open-addressing table does
+    // the same until it is full (icao_filter.c:76-79, 101-106): stay well clear of that, else replay on the host.
+    const uint32_t nnew = cnt[kCntNewAdders];
+    if (nnew > rsb_ctx::kNewAddersCap || c->replay.filter().active_slots_used() + 2 * (uint64_t)nnew + 1 >= IcaoFilter::kSlots) {
+        c->filter_dirty = true;
+        return 0;
+    }
+    if (nnew) {
+        c->h_new_adders.resize(nnew);
+        HIP_TRY(c, hipMemcpy(c->h_new_adders.data(), c->d_new_adders, nnew * sizeof(uint2), hipMemcpyDeviceToHost));
+        std::sort(c->h_new_adders.begin(), c->h_new_adders.end(), [](const uint2 &x, const uint2 &y) { return x.x < y.x; });
+        for (const uint2 &e : c->h_new_adders) c->replay.filter().add(e.y);  // in the order the reference learns them
+    }
+    return 1;
 }
 
 const CrcTables &tables_for(int fix_bits) {
@@ -152,7 +242,7 @@ void rsb_destroy(rsb_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1],
                     c->d_items, c->d_region_counts, c->d_skeys[0], c->d_skeys[1], c->d_sinfo[0], c->d_sinfo[1], c->d_sort_temp, c->d_surv_g, c->d_surv, c->d_ac, c->d_bitmap, c->d_counters, c->d_block_sums, c->d_carry,
-                    c->d_stage, c->d_mag, c->d_sums};
+                    c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_new_adders, c->d_addr_upload};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t ev : c->ev)
@@ -180,6 +270,7 @@ int rsb_filter_add(rsb_ctx *c, uint32_t addr) {
     HIP_TRY(c, hipMemcpy(&word, c->d_bitmap + (addr >> 5), 4, hipMemcpyDeviceToHost));
     word |= 1u << (addr & 31);
     HIP_TRY(c, hipMemcpy(c->d_bitmap + (addr >> 5), &word, 4, hipMemcpyHostToDevice));
+    c->filter_dirty = true;
     return RSB_OK;
 }
 
@@ -187,6 +278,7 @@ int rsb_filter_expire(rsb_ctx *c) {
     if (!c) return RSB_EINVAL;
     // the device bitmap stays a superset (it only ever grows), which is all the prune needs
     c->replay.filter().expire();
+    c->filter_dirty = true;
     return RSB_OK;
 }
 
@@ -248,62 +340,119 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
         c->finished = true;
         return RSB_EOVERFLOW;
     }
-    // kept items -> sorted -> distinct offsets -> full candidate records
+    const uint32_t n_items = cnt[kCntSurvItems];
+    const BatchArgs &a = c->pending_args;
     HIP_TRY(c, hipEventRecord(c->ev[4], s));
-    HIP_TRY(c, launch_sort_unique_finalize(c->pending_args, cnt[kCntSurvItems], c->d_sort_temp, c->sort_temp_bytes, &c->sorted_buf, s));
+    HIP_TRY(c, launch_sort(a, n_items, c->d_sort_temp, c->sort_temp_bytes, &c->sorted_buf, s));
     HIP_TRY(c, hipEventRecord(c->ev[5], s));
-    if (c->pending_n % kBlock == 0 && c->pending_n) {
-        // the next batch's 326-sample overlap (sdr_ifile.c:199-201); only now, the finalize kernel still read the old one
-        const unsigned bps = (c->cfg.input_format == RSB_UC8) ? 2 : 4;
-        HIP_TRY(c, hipMemcpyAsync(c->d_carry, (const char *)c->pending_args.iq + (c->pending_n - kTrailing) * bps, (size_t)kTrailing * bps,
-                                  hipMemcpyDeviceToDevice, s));
+
+    // the sequential half: on the device, unless asked otherwise or the device path declines the batch
+    const size_t nblocks = (size_t)((c->pending_n + kBlock - 1) / kBlock);
+    c->h_blk_counts.resize(nblocks + 1);
+    int on_device = 0;
+    c->timing.replay_iterations = 0;
+    if (!c->host_replay_only && !a.emit_dead && !a.keep_all) {
+        on_device = device_replay(c, n_items, s, cnt);
+        if (on_device < 0) return on_device;
     }
     uint32_t nsurv = 0;
-    HIP_TRY(c, hipMemcpyAsync(&nsurv, c->d_counters + kCntSurvivors, sizeof(nsurv), hipMemcpyDeviceToHost, s));
+    if (!on_device) {
+        // kept items -> distinct offsets -> full candidate records for the host replay
+        HIP_TRY(c, launch_unique_finalize(a, n_items, c->sorted_buf, c->d_sort_temp, c->sort_temp_bytes, s));
+        HIP_TRY(c, hipMemcpyAsync(&nsurv, c->d_counters + kCntSurvivors, sizeof(nsurv), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[6], s));
+    if (c->pending_n % kBlock == 0 && c->pending_n) {
+        // the next batch's 326-sample overlap (sdr_ifile.c:199-201); only now, the kernels above still read the old one
+        const unsigned bps = (c->cfg.input_format == RSB_UC8) ? 2 : 4;
+        HIP_TRY(c, hipMemcpyAsync(c->d_carry, (const char *)a.iq + (c->pending_n - kTrailing) * bps, (size_t)kTrailing * bps, hipMemcpyDeviceToDevice, s));
+    }
     HIP_TRY(c, hipStreamSynchronize(s));
-    if (nsurv > c->surv_cap) {
+    if (!on_device && nsurv > c->surv_cap) {
         char buf[200];
         std::snprintf(buf, sizeof(buf), "device queue overflow: surviving offsets %u/%u (lower rsb_config.queue_div)", nsurv, c->surv_cap);
         c->err = buf;
         c->finished = true;
         return RSB_EOVERFLOW;
     }
-    cnt[kCntSurvivors] = nsurv;
-    c->h_surv.resize(nsurv);
-    c->h_ac.resize(cnt[kCntAc]);
-    if (nsurv) HIP_TRY(c, hipMemcpyAsync(c->h_surv.data(), c->d_surv, nsurv * sizeof(Survivor), hipMemcpyDeviceToHost, s));
-    if (cnt[kCntAc]) HIP_TRY(c, hipMemcpyAsync(c->h_ac.data(), c->d_ac, cnt[kCntAc] * sizeof(AcCand), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    if (on_device && cnt[kCntAccepted] > c->out_cap) {
+        char buf[200];
+        std::snprintf(buf, sizeof(buf), "device queue overflow: messages %u/%u (lower rsb_config.queue_div)", cnt[kCntAccepted], c->out_cap);
+        c->err = buf;
+        c->finished = true;
+        c->filter_dirty = true;
+        return RSB_EOVERFLOW;
+    }
 
-    float finalize_ms = 0;
+    const auto t_copy = std::chrono::steady_clock::now();
+    const uint32_t nac = cnt[kCntAc];
+    c->h_ac.resize(nac);
+    if (nac) HIP_TRY(c, hipMemcpyAsync(c->h_ac.data(), c->d_ac, nac * sizeof(AcCand), hipMemcpyDeviceToHost, s));
+    size_t n = 0;            // messages of this batch
+    bool delivered = false;  // already in out[]
+    rsb_stats &st = c->replay.stats();
+    if (on_device) {
+        const uint32_t nacc = cnt[kCntAccepted];
+        if (nac == 0) {
+            // nothing to interleave: straight into the caller's buffer
+            n = nacc;
+            const size_t ncopy = n < cap ? n : cap;
+            if (ncopy) HIP_TRY(c, hipMemcpyAsync(out, c->d_surv, ncopy * sizeof(rsb_message), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            delivered = true;
+        } else {
+            c->dev_msgs.resize(nacc);
+            if (nacc) HIP_TRY(c, hipMemcpyAsync(c->dev_msgs.data(), c->d_surv, (size_t)nacc * sizeof(rsb_message), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+        }
+        for (int e = 0; e < 3; ++e) st.demod_accepted[e] += cnt[kCntAccE0 + e];
+    } else {
+        cnt[kCntSurvivors] = nsurv;
+        c->h_surv.resize(nsurv);
+        if (nsurv) HIP_TRY(c, hipMemcpyAsync(c->h_surv.data(), c->d_surv, nsurv * sizeof(Survivor), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    c->timing.copy_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_copy).count();
+
+    float ms = 0;
     (void)hipEventElapsedTime(&c->timing.scan_ms, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&c->timing.prune_ms, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&c->timing.modeac_ms, c->ev[2], c->ev[3]);
     (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[3]);
-    (void)hipEventElapsedTime(&finalize_ms, c->ev[4], c->ev[5]);
-    c->timing.prune_ms += finalize_ms;
-    c->timing.total_ms += finalize_ms;
+    (void)hipEventElapsedTime(&c->timing.sort_ms, c->ev[4], c->ev[5]);
+    (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]);
+    c->timing.device_replay_ms = on_device ? ms : 0.0f;
+    if (!on_device) c->timing.prune_ms += ms;  // the candidate re-slice belongs to the prune stage of the host path
+    c->timing.total_ms += c->timing.sort_ms + ms;
+    c->timing.replay_on_device = on_device;
 
     const auto t0 = std::chrono::steady_clock::now();
-    c->msgs.clear();
-    c->replay.run_batch(c->stream_pos, c->h_surv, c->h_ac, c->msgs);
+    if (!delivered) {
+        c->msgs.clear();
+        if (on_device)
+            c->replay.merge_modeac(c->stream_pos, c->dev_msgs, c->h_blk_counts.data(), nblocks, c->h_ac, c->msgs);
+        else
+            c->replay.run_batch(c->stream_pos, c->h_surv, c->h_ac, c->msgs);
+        n = c->msgs.size();
+        if (!on_device && !c->host_replay_only) c->filter_dirty = true;  // the host moved the filter on
+    }
     c->timing.replay_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
-    rsb_stats &st = c->replay.stats();
     st.samples_processed += c->pending_n;
     st.gated_offsets += cnt[kCntGated];
     st.live_candidates += cnt[kCntItemsTotal];
-    st.survivors += cnt[kCntSurvivors];
+    st.survivors += on_device ? cnt[kCntAccepted] : cnt[kCntSurvivors];
     st.modeac_candidates += cnt[kCntAc];
 
     c->stream_pos += c->pending_n;
     if (c->pending_n % kBlock != 0) c->finished = true;
     if (c->pending_n % kBlock == 0 && c->pending_n) c->carry_valid = 1;
 
-    const size_t n = c->msgs.size();
     if (n_out) *n_out = n;
-    const size_t ncopy = n < cap ? n : cap;
-    if (ncopy) std::memcpy(out, c->msgs.data(), ncopy * sizeof(rsb_message));
+    if (!delivered) {
+        const size_t ncopy = n < cap ? n : cap;
+        if (ncopy) std::memcpy(out, c->msgs.data(), ncopy * sizeof(rsb_message));
+    }
     if (n > cap) {
         c->err = "rsb_collect: output buffer too small";
         return RSB_EOVERFLOW;

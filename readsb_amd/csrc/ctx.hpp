@@ -50,6 +50,18 @@ struct rsb_ctx {
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
     uint16_t *d_mag = nullptr;  // drop-in block path
+    // device replay
+    uint32_t *d_first_add[2] = {nullptr, nullptr};  // 2 x 2^24 "first added at" tables (kernels.hpp ReplayArgs)
+    int first_cur = 0;
+    bool filter_dirty = true;       // the tables do not mirror replay.filter() (reset, external add / expire, host replay)
+    bool host_replay_only = false;  // RSB_FLAG_HOST_REPLAY
+    uint32_t *d_blk_counts = nullptr;
+    uint2 *d_new_adders = nullptr;
+    uint32_t *d_addr_upload = nullptr;
+    uint32_t out_cap = 0;
+    static constexpr uint32_t kNewAddersCap = 8192;
+    std::vector<uint32_t> h_blk_counts, h_addrs;
+    std::vector<uint2> h_new_adders;
     uint64_t *d_sums = nullptr;
 
     // stream state
@@ -60,12 +72,12 @@ struct rsb_ctx {
     hipStream_t pending_stream = nullptr;
     rsb::BatchArgs pending_args;
 
-    hipEvent_t ev[6];
+    hipEvent_t ev[8];
     rsb_timing timing;
     std::string err;
     std::vector<rsb::Survivor> h_surv;
     std::vector<rsb::AcCand> h_ac;
-    std::vector<rsb_message> msgs;
+    std::vector<rsb_message> msgs, dev_msgs;
 
     rsb::BatchArgs batch_args(const void *iq, uint64_t n, int fmt) const {
         rsb::BatchArgs a;

@@ -782,6 +782,221 @@ __global__ __launch_bounds__(64) void k_finalize(const BatchArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// device replay: the sequential rules of demod_2400.c:289-374 on the sorted kept items
+
+// scoreModesMessage's result for an item given the filter's answer (mode_s.c:336-407)
+__device__ __forceinline__ int combo_score(uint32_t combo, bool member) {
+    if (combo <= kComboApLong) return member ? 1000 : -1;
+    if (combo == kComboCommB) return member ? 1000 : -2;
+    if (combo <= kComboDf11Iid0 + 1) return (member ? 1600 : 750) / (int)(combo - kComboDf11Iid0 + 1);
+    if (combo <= kComboDf11IidX + 1) return member ? 1000 / (int)(combo - kComboDf11IidX + 1) : -1;
+    const uint32_t sub = (combo - kComboDf17) % 5u;  // 0: clean, 1/2: one bit, 3/4: two bits
+    return (member ? 1800 : 1400) / (int)((sub + 1) / 2 + 1);
+}
+// does decodeModesMessage accept the winning phase (mode_s.c:461-466, 495-498, 524-526, 541-550)?
+__device__ __forceinline__ bool combo_decodes(uint32_t combo, bool member) {
+    if (combo <= kComboCommB) return member;
+    if (combo == kComboDf11Iid0 || combo == kComboDf11IidX) return true;
+    if (combo == kComboDf11Iid0 + 1 || combo == kComboDf11IidX + 1) return member;
+    const uint32_t sub = (combo - kComboDf17) % 5u;
+    return (sub == 2 || sub == 4) ? member : true;  // repaired AA differs from the received one: must be known
+}
+__device__ __forceinline__ bool combo_is_short(uint32_t combo) { return combo == kComboApShort || (combo >= kComboDf11Iid0 && combo <= kComboDf11IidX + 1); }
+__device__ __forceinline__ bool combo_adds(uint32_t combo) { return combo == kComboDf11Iid0 || combo == kComboDf17; }  // mode_s.c:717-726
+
+__global__ __launch_bounds__(kThreads) void k_replay_lookup(const ReplayArgs r) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads)
+        r.tval[i] = r.t_cur[item_value(r.info[i])];
+}
+
+__device__ __forceinline__ uint32_t first_key_at_or_after(const uint64_t *keys, uint32_t n, uint64_t key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// One thread per 131072-sample block (one demodulate2400 call): offsets ascending, best phase by
+// strict '>' (demod_2400.c:290-301), decode, skip the message's samples (:371).
+__global__ __launch_bounds__(64) void k_replay_walk(const ReplayArgs r) {
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= r.nblocks) return;
+    uint32_t i = first_key_at_or_after(r.keys, r.n_items, ((uint64_t)b * kBlock) << 3);
+    const uint32_t end = first_key_at_or_after(r.keys, r.n_items, ((uint64_t)(b + 1) * kBlock) << 3);
+    uint32_t next_j = 0, accepted = 0;
+    while (i < end) {
+        const uint32_t g = (uint32_t)(r.keys[i] >> 3);
+        int best = -2;
+        uint32_t best_i = i, e = i;
+        for (; e < end && (uint32_t)(r.keys[e] >> 3) == g; ++e) {
+            r.acc[e] = 0;
+            const uint32_t combo = item_combo(r.info[e]);
+            if (combo == kComboMarker) continue;
+            const int sc = combo_score(combo, r.tval[e] <= g);
+            if (sc > best) {
+                best = sc;
+                best_i = e;
+            }
+        }
+        if (g >= next_j && best >= 0) {
+            const uint32_t info = r.info[best_i], combo = item_combo(info);
+            if (combo_decodes(combo, r.tval[best_i] <= g)) {
+                r.acc[best_i] = (uint32_t)best + 1;
+                ++accepted;
+                next_j = g + (combo_is_short(combo) ? 134u : 268u) + 1;
+                if (combo_adds(combo)) atomicMin(&r.t_next[item_value(info)], g + 1);
+            }
+        }
+        i = e;
+    }
+    r.blk_counts[b] = accepted;
+}
+
+// over the items that can add an address: did the table move / reset / list / fold
+__global__ __launch_bounds__(kThreads) void k_replay_compare(const ReplayArgs r, uint32_t *changed) {
+    bool any = false;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads) {
+        const uint32_t info = r.info[i];
+        if (!combo_adds(item_combo(info))) continue;
+        const uint32_t v = item_value(info);
+        any |= r.t_cur[v] != r.t_next[v];
+    }
+    if (any) *changed = 1;
+}
+__global__ __launch_bounds__(kThreads) void k_replay_reset(const ReplayArgs r, uint32_t *table) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads) {
+        const uint32_t info = r.info[i];
+        if (!combo_adds(item_combo(info))) continue;
+        const uint32_t v = item_value(info);
+        if (table[v] != 0) table[v] = kNever;  // 0 = known before this batch: stays
+    }
+}
+__global__ __launch_bounds__(kThreads) void k_replay_list(const ReplayArgs r, uint32_t *counters) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads) {
+        const uint32_t info = r.info[i];
+        if (!combo_adds(item_combo(info)) || r.acc[i] == 0) continue;
+        const uint32_t v = item_value(info), g1 = (uint32_t)(r.keys[i] >> 3) + 1;
+        if (r.t_cur[v] == g1) {
+            const uint32_t slot = atomicAdd(&counters[kCntNewAdders], 1u);
+            if (slot < r.new_adders_cap) r.new_adders[slot] = make_uint2(g1, v);
+        }
+    }
+}
+__global__ __launch_bounds__(kThreads) void k_replay_fold(const ReplayArgs r) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads) {
+        const uint32_t info = r.info[i];
+        if (!combo_adds(item_combo(info))) continue;
+        const uint32_t v = item_value(info);
+        if (r.t_cur[v] != kNever) {
+            r.t_cur[v] = 0;
+            r.t_next[v] = 0;
+        }
+    }
+}
+__global__ __launch_bounds__(kThreads) void k_filter_fill(uint32_t *t0, uint32_t *t1, const uint32_t *addrs, uint32_t n) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i == 0) t0[0] = t1[0] = 0;  // icaoFilterTest(0) hits an empty slot (icao_filter.c:101-107)
+    if (i < n) t0[addrs[i]] = t1[addrs[i]] = 0;
+}
+
+// One wavefront per accepted message: re-slice the winning phase (lane G = bits 5G..5G+4), repair it
+// (crc.c:410-418), fill in the fields of mode_s.c:424-562 and the signal level of demod_2400.c:342-354.
+template <int FMT>
+__global__ __launch_bounds__(kThreads) void k_replay_emit(const BatchArgs a, const ReplayArgs r) {
+    __shared__ uint32_t sbs[112];
+    __shared__ __attribute__((aligned(16))) uint16_t win[kThreads / 64][kHalo];
+    __shared__ uint32_t grp[kThreads / 64][28];
+    __shared__ __attribute__((aligned(8))) uint8_t rec[kThreads / 64][56];
+    if (threadIdx.x < 112) sbs[threadIdx.x] = a.tab.sbs[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t nacc = a.counters[kCntAccepted];
+    if (nacc > r.out_cap) nacc = r.out_cap;
+    uint32_t by_errors[3] = {0, 0, 0};
+    for (uint32_t mi = blockIdx.x * (kThreads / 64) + wave; mi < nacc; mi += gridDim.x * (kThreads / 64)) {
+        const uint32_t idx = r.acc_idx[mi];
+        const uint64_t key = r.keys[idx];
+        const uint32_t info = r.info[idx], score = r.acc[idx] - 1;
+        const uint32_t g = (uint32_t)(key >> 3), phase = (uint32_t)key & 7u, combo = item_combo(info);
+        const bool lng = !combo_is_short(combo);
+        const uint32_t nbits = lng ? 112 : 56, ngroups = lng ? 23 : 12;
+        wave_sync();
+        for (uint32_t k = lane; k < (uint32_t)kHalo; k += 64) win[wave][k] = (uint16_t)stream_mag<FMT>(a, (int64_t)g + k);
+        wave_sync();
+        uint32_t b = 0, syn = 0;
+        if (lane < ngroups) {
+            const RotSlicer rs(phase);
+            b = rs.group(win[wave], 19, (int)lane);
+#pragma unroll
+            for (uint32_t j = 0; j < 5; ++j) {
+                const uint32_t k = 5 * lane + j;
+                if (k >= nbits) b &= ~(16u >> j);
+                else if ((b >> (4 - j)) & 1) syn ^= sbs[k + 112 - nbits];  // crc.c:59-64, the CRC is linear
+            }
+        }
+        if (lane < 28) grp[wave][lane] = b;
+        // demod_2400.c:345-351
+        const uint32_t signal_len = nbits * 12 / 5;
+        uint64_t pw = 0;
+        for (uint32_t k = lane; k < signal_len; k += 64) pw += (uint64_t)win[wave][19 + k] * win[wave][19 + k];
+        for (int off = 32; off > 0; off >>= 1) {
+            syn ^= __shfl_xor(syn, off, 64);
+            pw += __shfl_xor(pw, off, 64);
+        }
+        wave_sync();
+        const uint32_t df = grp[wave][0];
+        // repair: DF11 on the syndrome without its IID bits (mode_s.c:475-489), DF17/18 on all of it (:508-518)
+        uint32_t fix = 0;
+        if (combo >= kComboDf11Iid0) {
+            const uint32_t s = (combo <= kComboDf11IidX + 1) ? (syn & 0xffff80u) : syn;
+            if (s) fix = diagnose(a.tab, lng ? 1 : 0, s);
+            if (fix == 0xffffffffu) fix = 0;  // cannot happen for an item the scan classified; keep the frame as sliced
+        }
+        const uint32_t nerr = fix & 0xffu;
+        if (lane < 14) {
+            uint32_t byte = 0;
+            if (lane < nbits / 8) {
+                const uint32_t G0 = (8 * lane) / 5, d = 8 * lane - 5 * G0;
+                const uint32_t v = (grp[wave][G0] << 10) | (grp[wave][G0 + 1] << 5) | grp[wave][G0 + 2];
+                byte = (v >> (7 - d)) & 0xffu;
+                for (uint32_t e = 0; e < nerr; ++e) {
+                    const uint32_t p = (fix >> (8 + 8 * e)) & 0xffu;
+                    if ((p >> 3) == lane) byte ^= 1u << (7 - (p & 7));
+                }
+            }
+            rec[wave][8 + lane] = (uint8_t)byte;
+        }
+        wave_sync();
+        if (lane == 0) {
+            uint8_t *o = rec[wave];
+            const uint64_t gg = r.g0 + g;
+            *(uint64_t *)(o + 0) = 5 * gg + (8 + 56) * 12 + (phase + 4);  // demod_2400.c:320
+            o[22] = (uint8_t)nbits;
+            o[23] = (uint8_t)df;
+            const bool parity_addr = combo <= kComboCommB;
+            const uint32_t aa = ((uint32_t)o[9] << 16) | ((uint32_t)o[10] << 8) | o[11];
+            *(uint32_t *)(o + 24) = syn;
+            *(int32_t *)(o + 28) = (int32_t)nerr;
+            *(uint32_t *)(o + 32) = parity_addr ? syn : aa;
+            *(int32_t *)(o + 36) = (int32_t)score;
+            *(int32_t *)(o + 40) = parity_addr ? 3 : (combo <= kComboDf11IidX + 1 ? 4 : 7);  // datasource_t
+            *(uint32_t *)(o + 44) = (combo >= kComboDf11Iid0 && combo <= kComboDf11IidX + 1) ? (syn & 0x7fu) : 0u;
+            const double signal_power = (double)pw / 65535.0 / 65535.0;
+            *(double *)(o + 48) = signal_power / (double)signal_len;
+        }
+        wave_sync();
+        if (lane < 14) ((uint32_t *)&r.out[mi])[lane] = ((const uint32_t *)rec[wave])[lane];
+        ++by_errors[nerr < 3 ? nerr : 2];
+    }
+    if (lane == 0)
+        for (int e = 0; e < 3; ++e)
+            if (by_errors[e]) atomicAdd(&a.counters[kCntAccE0 + e], by_errors[e]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Mode A/C
 
@@ -964,26 +1179,35 @@ hipError_t launch_prune(const BatchArgs &a, hipStream_t s) {
 }
 
 size_t sort_temp_bytes(uint32_t max_items) {
-    size_t sort_bytes = 0, uniq_bytes = 0;
+    size_t sort_bytes = 0, uniq_bytes = 0, flag_bytes = 0;
     hipcub::DoubleBuffer<uint64_t> k(nullptr, nullptr);
     hipcub::DoubleBuffer<uint32_t> v(nullptr, nullptr);
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k, v, (int)max_items, 0, 35);
     (void)hipcub::DeviceSelect::Unique(nullptr, uniq_bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)max_items);
-    return (sort_bytes > uniq_bytes ? sort_bytes : uniq_bytes) + 256;
+    (void)hipcub::DeviceSelect::Flagged(nullptr, flag_bytes, hipcub::CountingInputIterator<uint32_t>(0), (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                        (uint32_t *)nullptr, (int)max_items);
+    size_t m = sort_bytes > uniq_bytes ? sort_bytes : uniq_bytes;
+    if (flag_bytes > m) m = flag_bytes;
+    return m + 256;
 }
 
-hipError_t launch_sort_unique_finalize(const BatchArgs &a, uint32_t n_items, void *temp, size_t temp_bytes, int *sorted_buf, hipStream_t s) {
+hipError_t launch_sort(const BatchArgs &a, uint32_t n_items, void *temp, size_t temp_bytes, int *sorted_buf, hipStream_t s) {
     *sorted_buf = 0;
-    if (n_items == 0) return hipMemsetAsync(&a.counters[kCntSurvivors], 0, sizeof(uint32_t), s);
+    if (n_items == 0) return hipSuccess;
     hipcub::DoubleBuffer<uint64_t> k(a.skeys[0], a.skeys[1]);
     hipcub::DoubleBuffer<uint32_t> v(a.sinfo[0], a.sinfo[1]);
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k, v, (int)n_items, 0, 35, s);
     if (e != hipSuccess) return e;
     *sorted_buf = (k.Current() == a.skeys[1]) ? 1 : 0;
+    return hipSuccess;
+}
+
+hipError_t launch_unique_finalize(const BatchArgs &a, uint32_t n_items, int sorted_buf, void *temp, size_t temp_bytes, hipStream_t s) {
+    if (n_items == 0) return hipMemsetAsync(&a.counters[kCntSurvivors], 0, sizeof(uint32_t), s);
     // distinct offsets, ascending: the other key buffer is free now and serves as scratch for g
-    uint32_t *gtmp = (uint32_t *)a.skeys[*sorted_buf ^ 1];
-    hipLaunchKernelGGL(k_keys_to_g, dim3(512), dim3(kThreads), 0, s, k.Current(), gtmp, n_items);
-    e = hipGetLastError();
+    uint32_t *gtmp = (uint32_t *)a.skeys[sorted_buf ^ 1];
+    hipLaunchKernelGGL(k_keys_to_g, dim3(512), dim3(kThreads), 0, s, a.skeys[sorted_buf], gtmp, n_items);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     e = hipcub::DeviceSelect::Unique(temp, temp_bytes, gtmp, a.surv_g, &a.counters[kCntSurvivors], (int)n_items, s);
     if (e != hipSuccess) return e;
@@ -991,6 +1215,52 @@ hipError_t launch_sort_unique_finalize(const BatchArgs &a, uint32_t n_items, voi
         hipLaunchKernelGGL(k_finalize<decltype(F)::value>, dim3(8192), dim3(64), 0, s, a);
         return hipGetLastError();
     });
+}
+
+namespace {
+inline unsigned item_grid(uint32_t n) {
+    const unsigned g = (n + kThreads - 1) / kThreads;
+    return g < 1 ? 1 : (g > 2048 ? 2048 : g);
+}
+}  // namespace
+
+hipError_t launch_replay_iteration(const BatchArgs &a, const ReplayArgs &r, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(&a.counters[kCntChanged], 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    if (r.n_items) hipLaunchKernelGGL(k_replay_lookup, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);
+    hipLaunchKernelGGL(k_replay_walk, dim3((r.nblocks + 63) / 64), dim3(64), 0, s, r);
+    if (r.n_items) hipLaunchKernelGGL(k_replay_compare, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, &a.counters[kCntChanged]);
+    return hipGetLastError();
+}
+
+hipError_t launch_replay_reset(const BatchArgs &, const ReplayArgs &r, uint32_t *table, hipStream_t s) {
+    if (r.n_items) hipLaunchKernelGGL(k_replay_reset, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, table);
+    return hipGetLastError();
+}
+
+hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(&a.counters[kCntAccepted], 0, 5 * sizeof(uint32_t), s);  // accepted, new adders, by errors
+    if (e != hipSuccess || r.n_items == 0) return e;
+    hipLaunchKernelGGL(k_replay_list, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, a.counters);
+    hipLaunchKernelGGL(k_replay_fold, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = hipcub::DeviceSelect::Flagged(temp, temp_bytes, hipcub::CountingInputIterator<uint32_t>(0), r.acc, r.acc_idx, &a.counters[kCntAccepted],
+                                      (int)r.n_items, s);
+    if (e != hipSuccess) return e;
+    return by_format(a.fmt, [&](auto F) {
+        hipLaunchKernelGGL(k_replay_emit<decltype(F)::value>, dim3(2048), dim3(kThreads), 0, s, a, r);
+        return hipGetLastError();
+    });
+}
+
+hipError_t launch_filter_rebuild(uint32_t *t0, uint32_t *t1, const uint32_t *addrs_dev, uint32_t n, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(t0, 0xff, sizeof(uint32_t) << 24, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(t1, 0xff, sizeof(uint32_t) << 24, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_filter_fill, dim3((n + kThreads) / kThreads), dim3(kThreads), 0, s, t0, t1, addrs_dev, n);
+    return hipGetLastError();
 }
 
 hipError_t launch_modeac(const BatchArgs &a, hipStream_t s) {

@@ -22,7 +22,13 @@ enum : int {
     kCntSlowPath,      // candidates / items that overflowed an LDS queue and took the per-thread path
     kCntOverflow,      // item regions that overflowed (results incomplete -> RSB_EOVERFLOW)
     kCntItemsTotal,    // all items (sum over regions), for statistics
-    kCntCount = 8
+    kCntChanged,       // device replay: the first-add table moved in this iteration
+    kCntAccepted,      // device replay: messages accepted
+    kCntNewAdders,     // device replay: addresses the filter learned in this batch
+    kCntAccE0,         // device replay: accepted messages by corrected bits (0, 1, 2)
+    kCntAccE1,
+    kCntAccE2,
+    kCntCount = 16
 };
 
 struct DeviceTables {      // read-only, built once per context
@@ -66,13 +72,43 @@ struct BatchArgs {
     int stage_limit;         // debug/ablation only (RSB_STAGE_LIMIT): stop the scan kernel after stage k
 };
 
+// The sequential half on the device (DESIGN.md "device replay"): the greedy scan of demod_2400.c:289-374
+// walks each 131072-sample block with one thread over the sorted kept items, and the coupling through
+// the ICAO filter (mode_s.c:717-726) is resolved by iterating a "first added at" table to its fixed point.
+struct ReplayArgs {
+    const uint64_t *keys;    // sorted: g << 3 | phase
+    const uint32_t *info;    // the items' info words, same order
+    uint32_t n_items;
+    uint32_t *tval;          // per item: first_add[value] as of this iteration
+    uint32_t *acc;           // per item: score + 1 if this (offset, phase) is decoded and accepted, else 0
+    uint32_t *acc_idx;       // indices of the accepted items, ascending
+    uint32_t *t_cur;         // 2^24 x u32: 0 = in the filter before this batch, g + 1 = first added by the message at
+    uint32_t *t_next;        //             offset g of this batch, 0xffffffff = never
+    uint32_t *blk_counts;    // accepted messages per 131072-sample block
+    uint32_t nblocks;
+    uint2 *new_adders;       // (g + 1, address) of every address learned in this batch
+    uint32_t new_adders_cap;
+    rsb_message *out;
+    uint32_t out_cap;
+    uint64_t g0;             // stream position of the batch
+};
+constexpr uint32_t kNever = 0xffffffffu;
+
 int scan_grid_size(int device);
 hipError_t launch_scan(const BatchArgs &a, int grid, hipStream_t s);
 hipError_t launch_prune(const BatchArgs &a, hipStream_t s);
 // sorts the n_items kept items by (g, phase), derives the ascending list of distinct offsets
 // (count -> counters[kCntSurvivors]) and re-slices each of them into a Survivor record
 size_t sort_temp_bytes(uint32_t max_items);
-hipError_t launch_sort_unique_finalize(const BatchArgs &a, uint32_t n_items, void *temp, size_t temp_bytes, int *sorted_buf, hipStream_t s);
+hipError_t launch_sort(const BatchArgs &a, uint32_t n_items, void *temp, size_t temp_bytes, int *sorted_buf, hipStream_t s);
+hipError_t launch_unique_finalize(const BatchArgs &a, uint32_t n_items, int sorted_buf, void *temp, size_t temp_bytes, hipStream_t s);
+// device replay: one fixed-point iteration (lookup, walk, compare; counters[kCntChanged] tells whether to go on),
+// the reset of the table that becomes t_next, and the final list / fold / compact / emit step
+hipError_t launch_replay_iteration(const BatchArgs &a, const ReplayArgs &r, hipStream_t s);
+hipError_t launch_replay_reset(const BatchArgs &a, const ReplayArgs &r, uint32_t *table, hipStream_t s);
+hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s);
+// first-add tables := "never" everywhere, 0 for address 0 and the n given addresses
+hipError_t launch_filter_rebuild(uint32_t *t0, uint32_t *t1, const uint32_t *addrs_dev, uint32_t n, hipStream_t s);
 hipError_t launch_modeac(const BatchArgs &a, hipStream_t s);
 hipError_t launch_convert(int fmt, const void *iq, uint16_t *mag, uint64_t n, const uint16_t *lut, uint64_t *sums, hipStream_t s);
 

@@ -184,6 +184,19 @@ void IcaoFilter::expire() {  // icao_filter.c:151-158 (one flip)
     active_ = next;
 }
 
+void IcaoFilter::contents(std::vector<uint32_t> &out) const {
+    out.clear();
+    for (const uint32_t *t : {a_, b_})
+        for (uint32_t i = 0; i < kSize; ++i)
+            if (t[i]) out.push_back(t[i]);
+}
+
+uint32_t IcaoFilter::active_slots_used() const {
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < kSize; ++i) n += active_[i] != 0;
+    return n;
+}
+
 // =============================================================================== score / decode
 
 namespace {
@@ -363,6 +376,30 @@ void sort_by_g(std::vector<T> &v) {
 
 }  // namespace
 
+// demodulate2400AC's emission for one block: greedy skip (demod_2400.c:659) over its candidates
+static void replay_modeac_block(uint64_t g0, uint64_t blk_start, uint64_t blk_end, const std::vector<AcCand> &ac, size_t &ia, rsb_stats &stats,
+                                std::vector<rsb_message> &out) {
+    uint64_t next_f = 0;
+    for (; ia < ac.size() && g0 + ac[ia].g < blk_end; ++ia) {
+        const AcCand &c = ac[ia];
+        const uint64_t g = g0 + c.g;
+        if (g < next_f) continue;
+        rsb_message m;
+        std::memset(&m, 0, sizeof(m));
+        m.timestamp = 5 * blk_start + c.f2_clock / 5;  // demod_2400.c:649
+        // decodeModeAMessage, mode_ac.c:165-199
+        m.source = 1;  // SOURCE_MODE_AC
+        m.msgtype = 32;
+        m.msgbits = 16;
+        m.msg[0] = uint8_t(c.modeac >> 8);
+        m.msg[1] = uint8_t(c.modeac);
+        m.addr = (c.modeac & 0x0000FF7Fu) | (1u << 24);
+        next_f = g + 70;  // demod_2400.c:659 plus the loop's own ++
+        ++stats.demod_modeac;
+        out.push_back(m);
+    }
+}
+
 void Replayer::run_batch(uint64_t g0, std::vector<Survivor> &surv, std::vector<AcCand> &ac, std::vector<rsb_message> &out) {
     sort_by_g(surv);
     sort_by_g(ac);
@@ -406,25 +443,19 @@ void Replayer::run_batch(uint64_t g0, std::vector<Survivor> &surv, std::vector<A
             out.push_back(m);
         }
 
-        uint64_t next_f = 0;
-        for (; ia < ac.size() && g0 + ac[ia].g < blk_end; ++ia) {
-            const AcCand &c = ac[ia];
-            const uint64_t g = g0 + c.g;
-            if (g < next_f) continue;
-            rsb_message m;
-            std::memset(&m, 0, sizeof(m));
-            m.timestamp = 5 * blk_start + c.f2_clock / 5;  // demod_2400.c:649
-            // decodeModeAMessage, mode_ac.c:165-199
-            m.source = 1;  // SOURCE_MODE_AC
-            m.msgtype = 32;
-            m.msgbits = 16;
-            m.msg[0] = uint8_t(c.modeac >> 8);
-            m.msg[1] = uint8_t(c.modeac);
-            m.addr = (c.modeac & 0x0000FF7Fu) | (1u << 24);
-            next_f = g + 70;  // demod_2400.c:659 plus the loop's own ++
-            ++stats_.demod_modeac;
-            out.push_back(m);
-        }
+        replay_modeac_block(g0, blk_start, blk_end, ac, ia, stats_, out);
+    }
+}
+
+void Replayer::merge_modeac(uint64_t g0, const std::vector<rsb_message> &msgs, const uint32_t *blk_counts, size_t nblocks,
+                            std::vector<AcCand> &ac, std::vector<rsb_message> &out) {
+    sort_by_g(ac);
+    size_t im = 0, ia = 0;
+    for (size_t b = 0; b < nblocks; ++b) {
+        const uint64_t blk_start = g0 + b * kBlock;
+        out.insert(out.end(), msgs.begin() + im, msgs.begin() + im + blk_counts[b]);
+        im += blk_counts[b];
+        replay_modeac_block(g0, blk_start, blk_start + kBlock, ac, ia, stats_, out);
     }
 }
 

@@ -110,6 +110,10 @@ public:
     void add(uint32_t addr);
     bool test(uint32_t addr) const;
     void expire();
+    // for the device mirror: every address either generation holds, and how full the active table is
+    void contents(std::vector<uint32_t> &out) const;
+    uint32_t active_slots_used() const;
+    static constexpr uint32_t kSlots = 4096;
 
 private:
     static constexpr uint32_t kSize = 4096;
@@ -138,6 +142,10 @@ public:
     rsb_stats &stats() { return stats_; }
     // g0 = stream position of the batch (multiple of kBlock); records need not be sorted.
     void run_batch(uint64_t g0, std::vector<Survivor> &surv, std::vector<AcCand> &ac, std::vector<rsb_message> &out);
+    // After a device replay: msgs holds the batch's Mode S messages in scan order, blk_counts[b] of them per
+    // 131072-sample block; interleave each block's Mode A/C messages behind them (readsb.c:883-886).
+    void merge_modeac(uint64_t g0, const std::vector<rsb_message> &msgs, const uint32_t *blk_counts, size_t nblocks,
+                      std::vector<AcCand> &ac, std::vector<rsb_message> &out);
 
 private:
     CrcTables crc_;

@@ -11,29 +11,124 @@ from test_oracle import load_demod
 
 pytestmark = pytest.mark.gpu
 
+REPLAY = pytest.mark.parametrize("host_replay", [False, True], ids=["device_replay", "host_replay"])
 
+
+@REPLAY
 @pytest.mark.parametrize("name", GPU_SCENARIOS)
-def test_stream_matches_oracle_and_golden(name, built):
+def test_stream_matches_oracle_and_golden(name, host_replay, built):
     sc, kw = SCENARIOS[name]
     iq = generate(sc)
-    want, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
+    want, wst = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
     gold, _, _ = load_demod(name)  # what the unmodified reference produced for this input
     assert first_mismatch(gold, want) is None
-    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=1 << 23)
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=1 << 23, host_replay=host_replay)
     got = ch.process_host(iq)
     assert first_mismatch(want, got.view(REC_DTYPE)) is None
     st = ch.stats()
     assert st["samples_processed"] == sc.n_samples
+    assert st["demod_accepted"] == [wst["accepted0"], wst["accepted1"], wst["accepted2"]]
+    assert st["demod_modeac"] == wst["modeac"]
+    assert ch.timing()["replay_on_device"] == (0 if host_replay else 1)  # no silent change of path
     ch.close()
 
 
+@REPLAY
 @pytest.mark.parametrize("batch_blocks", [1, 3])
-def test_batched_stream_equals_one_shot(batch_blocks, built):
-    """Feeding the recording block-batch by block-batch (overlap carried on the device) changes nothing."""
+def test_batched_stream_equals_one_shot(batch_blocks, host_replay, built):
+    """Feeding the recording block-batch by block-batch (overlap and filter carried over) changes nothing."""
     sc, kw = SCENARIOS["dense_fix1_ac"]
     iq = generate(sc)
     want, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
-    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=batch_blocks * 131072)
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=batch_blocks * 131072,
+                            host_replay=host_replay)
     got = ch.process_stream_host(iq, batch_blocks)
     assert first_mismatch(want, got.view(REC_DTYPE)) is None
     ch.close()
+
+
+def _addresses(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return [int(x) for x in rng.choice(np.arange(1, 1 << 24), size=n, replace=False)]
+
+
+def test_prefilled_filter(built):
+    """--show-only style start-up adds (readsb.c:249-250) are seen by the device replay."""
+    sc, kw = SCENARIOS["mixed_fix1"]
+    iq = generate(sc)
+    cold, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
+    # every address the cold run ever reports, plus strangers: Address/Parity replies now decode from the start
+    adds = sorted(set(int(a) for a in cold["addr"]))[:64] + _addresses(100, 1)
+    orc = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"])
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=1 << 23)
+    for a in adds:
+        orc.filter_add(a)
+        ch.filter_add(a)
+    want, _ = orc.run_stream(iq, reset=False)
+    assert len(want) > len(cold)
+    got = ch.process_host(iq)
+    assert first_mismatch(want, got.view(REC_DTYPE)) is None
+    assert ch.timing()["replay_on_device"] == 1
+    ch.close()
+
+
+def test_nearly_full_filter_goes_to_the_host(built):
+    """Close to the 4096-slot capacity of the reference's table (icao_filter.c:76-79) set semantics end:
+    the batch must take the host replay, which keeps the table itself, and still match."""
+    sc, kw = SCENARIOS["cfg1_df11_df17"]
+    iq = generate(sc)
+    adds = _addresses(2040, 2)
+    orc = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"])
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=1 << 23)
+    for a in adds:
+        orc.filter_add(a)
+        ch.filter_add(a)
+    want, _ = orc.run_stream(iq, reset=False)
+    got = ch.process_host(iq)
+    assert first_mismatch(want, got.view(REC_DTYPE)) is None
+    assert ch.timing()["replay_on_device"] == 0
+    ch.close()
+
+
+def test_filter_expiry_between_batches(built):
+    """icaoFilterExpire flips (icao_filter.c:147-161) between batches: device and host replay agree."""
+    sc, kw = SCENARIOS["mixed_fix1"]
+    iq = generate(sc).reshape(-1, 2)
+    cut = 8 * 131072
+    outs = []
+    for host_replay in (False, True):
+        ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=1 << 23, host_replay=host_replay)
+        parts = [ch.process_host(iq[:cut])]
+        ch.filter_expire()
+        ch.filter_expire()  # two flips: everything learned so far is forgotten
+        parts.append(ch.process_host(iq[cut:]))
+        outs.append(np.concatenate(parts))
+        ch.close()
+    assert outs[0].size == outs[1].size and outs[0].tobytes() == outs[1].tobytes()
+    # and forgetting matters: the second part differs from an uninterrupted run
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=1 << 23)
+    whole = np.concatenate([ch.process_host(iq[:cut]), ch.process_host(iq[cut:])])
+    ch.close()
+    want, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
+    assert first_mismatch(want, whole.view(REC_DTYPE)) is None
+    assert whole.size >= outs[0].size
+
+
+def test_external_add_between_batches(built):
+    """An icaoFilterAdd from outside between batches rebuilds the device tables from the host filter:
+    everything the device replay learned before must have reached the host filter."""
+    sc, kw = SCENARIOS["mixed_fix1"]
+    iq = generate(sc).reshape(-1, 2)
+    cut = 8 * 131072
+    outs = []
+    for host_replay in (False, True):
+        ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=1 << 23, host_replay=host_replay)
+        parts = [ch.process_host(iq[:cut])]
+        ch.filter_add(0xABCDEF)
+        parts.append(ch.process_host(iq[cut:]))
+        assert ch.timing()["replay_on_device"] == (0 if host_replay else 1)
+        outs.append(np.concatenate(parts))
+        ch.close()
+    assert outs[0].size == outs[1].size and outs[0].tobytes() == outs[1].tobytes()
+    want, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
+    assert first_mismatch(want, outs[0].view(REC_DTYPE)) is None  # 0xABCDEF matches nothing in this recording
