@@ -2,7 +2,7 @@
 """bench.py -- Msamples/s of demod+CRC (UC8 @ 2.4 MS/s) on N MI355X GPUs.
 
 One "step" = one pass of the whole hot path (IQ -> magnitude -> preamble gate -> 5-phase slicing
--> CRC/syndrome repair -> filter-superset prune -> host replay -> message list) over one
+-> CRC/syndrome repair -> filter-superset prune -> device replay -> message list in host memory) over one
 1-Gsample synthetic UC8 recording that is already resident in HBM (BASELINE.json configs[1]).
 With N > 1 every rank owns one independent recording/channel of the same size (weak scaling,
 SURVEY.md section 8e): the data path has no collective; RCCL is used for the barrier, the
@@ -105,7 +105,8 @@ def main() -> int:
     ch = readsb_amd.Channel(fmt="UC8", fix_bits=1, mode_ac=False, device=local_rank, max_batch_samples=n, queue_div=32)
     stream = torch.cuda.current_stream().cuda_stream
     cap = max(1 << 16, n // 512)
-    outbuf = np.zeros(cap, dtype=readsb_amd.MSG_DTYPE)
+    # the caller's result buffer: pinned, so the device -> host copy of the message list runs at link speed
+    outbuf = torch.empty(cap * readsb_amd.MSG_DTYPE.itemsize, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE)
 
     def step():
         ch.reset()
@@ -119,15 +120,16 @@ def main() -> int:
 
     for _ in range(args.warmup):
         msgs = step()
-    scan_ms, total_ms, replay_ms = [], [], []
+    keys = ("scan_ms", "prune_ms", "sort_ms", "device_replay_ms", "copy_ms", "replay_ms", "total_ms", "replay_iterations", "replay_on_device")
+    tm = {k: [] for k in keys}
+    scan_ms = tm["scan_ms"]
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         msgs = step()
         t = ch.timing()
-        scan_ms.append(t["scan_ms"])
-        total_ms.append(t["total_ms"])
-        replay_ms.append(t["replay_ms"])
+        for k in keys:
+            tm[k].append(t[k])
     barrier()
     dt = time.perf_counter() - t0
     nmsgs = int(msgs.size)
@@ -176,7 +178,10 @@ def main() -> int:
             "roofline": {"bound": "hbm", "kernel": "k_scan<UC8>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": 2 * n, "avg_launch_ms": scan_s * 1e3},
-            "stage_ms": {"scan": float(np.mean(scan_ms)), "all_kernels": float(np.mean(total_ms)), "host_replay": float(np.mean(replay_ms))},
+            "stage_ms": {"scan": float(np.mean(tm["scan_ms"])), "prune": float(np.mean(tm["prune_ms"])), "sort": float(np.mean(tm["sort_ms"])),
+                         "device_replay": float(np.mean(tm["device_replay_ms"])), "copy_out": float(np.mean(tm["copy_ms"])),
+                         "host": float(np.mean(tm["replay_ms"])), "all_kernels": float(np.mean(tm["total_ms"])),
+                         "replay_iterations": float(np.mean(tm["replay_iterations"])), "replay_on_device": int(min(tm["replay_on_device"]))},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seg)

@@ -142,7 +142,6 @@ int device_replay(rsb_ctx *c, uint32_t n_items, hipStream_t s, uint32_t cnt[kCnt
     r.keys = a.skeys[c->sorted_buf];
     r.info = a.sinfo[c->sorted_buf];
     r.n_items = n_items;
-    r.tval = a.surv_g;
     r.acc = a.sinfo[c->sorted_buf ^ 1];
     r.acc_idx = (uint32_t *)a.skeys[c->sorted_buf ^ 1];
     r.blk_counts = c->d_blk_counts;

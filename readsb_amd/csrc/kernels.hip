@@ -724,18 +724,49 @@ __global__ __launch_bounds__(kThreads) void k_prune(const BatchArgs a) {
     }
     if (threadIdx.x == 0 && n) atomicAdd(&a.counters[kCntItemsTotal], n);
     const ItemRec *items = a.items + (size_t)r * a.item_region;
-    for (uint32_t i = threadIdx.x; i < n; i += kThreads) {
-        const ItemRec rec = items[i];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto keeps = [&](const ItemRec &rec) {
         const uint32_t combo = item_combo(rec.info), v = item_value(rec.info);
-        bool keep = a.keep_all != 0 || combo == kComboMarker || !combo_needs_member(combo);
-        if (!keep) keep = (a.adder_bitmap[v >> 5] >> (v & 31)) & 1u;
-        if (keep) {
-            const uint32_t slot = atomicAdd(&a.counters[kCntSurvItems], 1u);
-            if (slot < a.surv_item_cap) {
-                a.skeys[0][slot] = ((uint64_t)rec.g << 3) | item_phase(rec.info);
-                a.sinfo[0][slot] = rec.info;
-            }
+        if (a.keep_all != 0 || combo == kComboMarker || !combo_needs_member(combo)) return true;
+        return ((a.adder_bitmap[v >> 5] >> (v & 31)) & 1u) != 0;
+    };
+    // Two passes, so that the shared output counter is bumped once per workgroup and not once per item or
+    // wavefront (same-address atomics retire at ~0.1 per ns): each wavefront owns a quarter of the region,
+    // counts its kept items, then writes them behind the workgroup's reservation.
+    __shared__ uint32_t wave_count[kThreads / 64];
+    __shared__ uint32_t block_base;
+    const uint32_t per_wave = (n + kThreads / 64 - 1) / (kThreads / 64);
+    const uint32_t w_lo = min(n, wave * per_wave), w_hi = min(n, w_lo + per_wave);
+    uint32_t mine = 0;
+    for (uint32_t base = w_lo; base < w_hi; base += 64) {
+        const uint32_t i = base + lane;
+        mine += (uint32_t)__popcll(__ballot(i < w_hi && keeps(items[i])));
+    }
+    if (lane == 0) wave_count[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < kThreads / 64; ++w) total += wave_count[w];
+        block_base = total ? atomicAdd(&a.counters[kCntSurvItems], total) : 0u;
+    }
+    __syncthreads();
+    uint32_t slot0 = block_base;
+    for (uint32_t w = 0; w < wave; ++w) slot0 += wave_count[w];
+    for (uint32_t base = w_lo; base < w_hi; base += 64) {
+        const uint32_t i = base + lane;
+        ItemRec rec{0, 0};
+        bool keep = false;
+        if (i < w_hi) {
+            rec = items[i];
+            keep = keeps(rec);
         }
+        const uint64_t km = __ballot(keep);
+        const uint32_t slot = slot0 + lanes_below(km);
+        if (keep && slot < a.surv_item_cap) {
+            a.skeys[0][slot] = ((uint64_t)rec.g << 3) | item_phase(rec.info);
+            a.sinfo[0][slot] = rec.info;
+        }
+        slot0 += (uint32_t)__popcll(km);
     }
 }
 
@@ -806,11 +837,6 @@ __device__ __forceinline__ bool combo_decodes(uint32_t combo, bool member) {
 __device__ __forceinline__ bool combo_is_short(uint32_t combo) { return combo == kComboApShort || (combo >= kComboDf11Iid0 && combo <= kComboDf11IidX + 1); }
 __device__ __forceinline__ bool combo_adds(uint32_t combo) { return combo == kComboDf11Iid0 || combo == kComboDf17; }  // mode_s.c:717-726
 
-__global__ __launch_bounds__(kThreads) void k_replay_lookup(const ReplayArgs r) {
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads)
-        r.tval[i] = r.t_cur[item_value(r.info[i])];
-}
-
 __device__ __forceinline__ uint32_t first_key_at_or_after(const uint64_t *keys, uint32_t n, uint64_t key) {
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
@@ -820,40 +846,69 @@ __device__ __forceinline__ uint32_t first_key_at_or_after(const uint64_t *keys, 
     return lo;
 }
 
-// One thread per 131072-sample block (one demodulate2400 call): offsets ascending, best phase by
-// strict '>' (demod_2400.c:290-301), decode, skip the message's samples (:371).
-__global__ __launch_bounds__(64) void k_replay_walk(const ReplayArgs r) {
-    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= r.nblocks) return;
-    uint32_t i = first_key_at_or_after(r.keys, r.n_items, ((uint64_t)b * kBlock) << 3);
-    const uint32_t end = first_key_at_or_after(r.keys, r.n_items, ((uint64_t)(b + 1) * kBlock) << 3);
-    uint32_t next_j = 0, accepted = 0;
-    while (i < end) {
-        const uint32_t g = (uint32_t)(r.keys[i] >> 3);
+// One wavefront per 131072-sample block (one demodulate2400 call).  64 items at a time: the lane on
+// the first item of an offset picks that offset's best phase by strict '>' (demod_2400.c:290-301) and
+// asks whether decodeModesMessage would take it; the offsets that could be accepted are then chained
+// in ascending order through the greedy skip (:371), which is the only sequential part.
+__global__ __launch_bounds__(kThreads) void k_replay_walk(const ReplayArgs r) {
+    __shared__ uint32_t cand_g[kThreads / 64][64];
+    __shared__ uint32_t cand_len[kThreads / 64][64];
+    __shared__ uint32_t cand_ok[kThreads / 64][64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * (kThreads / 64) + wave;
+    if (b >= r.nblocks) return;  // whole wavefronts leave; no workgroup barrier below
+    const uint32_t lo = first_key_at_or_after(r.keys, r.n_items, ((uint64_t)b * kBlock) << 3);
+    const uint32_t hi = first_key_at_or_after(r.keys, r.n_items, ((uint64_t)(b + 1) * kBlock) << 3);
+    uint32_t next_j = 0, accepted = 0;  // wave-uniform
+    for (uint32_t base = lo; base < hi; base += 64) {
+        const uint32_t i = base + lane;
+        bool cand = false;
+        uint32_t g = 0, best_i = 0, best_info = 0;
         int best = -2;
-        uint32_t best_i = i, e = i;
-        for (; e < end && (uint32_t)(r.keys[e] >> 3) == g; ++e) {
-            r.acc[e] = 0;
-            const uint32_t combo = item_combo(r.info[e]);
-            if (combo == kComboMarker) continue;
-            const int sc = combo_score(combo, r.tval[e] <= g);
-            if (sc > best) {
-                best = sc;
-                best_i = e;
+        if (i < hi) {
+            const uint64_t key = r.keys[i];
+            g = (uint32_t)(key >> 3);
+            if (i == lo || (uint32_t)(r.keys[i - 1] >> 3) != g) {
+                bool best_member = false;
+                for (uint32_t e = i; e < hi; ++e) {
+                    if (e != i && (uint32_t)(r.keys[e] >> 3) != g) break;
+                    r.acc[e] = 0;
+                    const uint32_t info = r.info[e], combo = item_combo(info);
+                    if (combo == kComboMarker) continue;
+                    const bool member = r.t_cur[item_value(info)] <= g;  // added by a message at an earlier offset
+                    const int sc = combo_score(combo, member);
+                    if (sc > best) {
+                        best = sc;
+                        best_i = e;
+                        best_info = info;
+                        best_member = member;
+                    }
+                }
+                cand = best >= 0 && combo_decodes(item_combo(best_info), best_member);
             }
         }
-        if (g >= next_j && best >= 0) {
-            const uint32_t info = r.info[best_i], combo = item_combo(info);
-            if (combo_decodes(combo, r.tval[best_i] <= g)) {
-                r.acc[best_i] = (uint32_t)best + 1;
-                ++accepted;
-                next_j = g + (combo_is_short(combo) ? 134u : 268u) + 1;
-                if (combo_adds(combo)) atomicMin(&r.t_next[item_value(info)], g + 1);
-            }
+        const uint64_t cm = __ballot(cand);
+        const uint32_t pos = lanes_below(cm), nc = (uint32_t)__popcll(cm);
+        wave_sync();
+        if (cand) {
+            cand_g[wave][pos] = g;
+            cand_len[wave][pos] = combo_is_short(item_combo(best_info)) ? 134u : 268u;
         }
-        i = e;
+        wave_sync();
+        for (uint32_t k = 0; k < nc; ++k) {  // every lane runs the same chain
+            const uint32_t cg = cand_g[wave][k];
+            const bool take = cg >= next_j;
+            if (take) next_j = cg + cand_len[wave][k] + 1;
+            if (lane == 0) cand_ok[wave][k] = take;
+            accepted += take;
+        }
+        wave_sync();
+        if (cand && cand_ok[wave][pos]) {
+            r.acc[best_i] = (uint32_t)best + 1;
+            if (combo_adds(item_combo(best_info))) atomicMin(&r.t_next[item_value(best_info)], g + 1);
+        }
     }
-    r.blk_counts[b] = accepted;
+    if (lane == 0) r.blk_counts[b] = accepted;
 }
 
 // over the items that can add an address: did the table move / reset / list / fold
@@ -1227,8 +1282,7 @@ inline unsigned item_grid(uint32_t n) {
 hipError_t launch_replay_iteration(const BatchArgs &a, const ReplayArgs &r, hipStream_t s) {
     hipError_t e = hipMemsetAsync(&a.counters[kCntChanged], 0, sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    if (r.n_items) hipLaunchKernelGGL(k_replay_lookup, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);
-    hipLaunchKernelGGL(k_replay_walk, dim3((r.nblocks + 63) / 64), dim3(64), 0, s, r);
+    hipLaunchKernelGGL(k_replay_walk, dim3((r.nblocks + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, s, r);
     if (r.n_items) hipLaunchKernelGGL(k_replay_compare, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, &a.counters[kCntChanged]);
     return hipGetLastError();
 }

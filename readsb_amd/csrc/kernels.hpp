@@ -79,7 +79,6 @@ struct ReplayArgs {
     const uint64_t *keys;    // sorted: g << 3 | phase
     const uint32_t *info;    // the items' info words, same order
     uint32_t n_items;
-    uint32_t *tval;          // per item: first_add[value] as of this iteration
     uint32_t *acc;           // per item: score + 1 if this (offset, phase) is decoded and accepted, else 0
     uint32_t *acc_idx;       // indices of the accepted items, ascending
     uint32_t *t_cur;         // 2^24 x u32: 0 = in the filter before this batch, g + 1 = first added by the message at
