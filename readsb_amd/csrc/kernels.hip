@@ -64,6 +64,13 @@ __device__ __forceinline__ uint32_t stream_mag(const BatchArgs &a, int64_t s) {
     return mag_of<FMT>(a.iq, (uint64_t)s, a.tab.uc8_lut);
 }
 
+// LDS magnitude arrays hold "biased" magnitudes, mag ^ 0x8000, i.e. mag - 32768 as int16.  The taps of
+// every correlator sum to zero (5-3-2, 4-1-3, 3+1-4, 2+3-5, 1+5-5-1), so the correlators give exactly the
+// same values on biased samples, and the signed 16-bit dot product v_dot2_i32_i16 applies to sample
+// pairs as they lie in LDS.  Comparisons between samples become signed comparisons.
+constexpr uint32_t kBias = 0x8000u, kBias2 = 0x80008000u;
+__device__ __forceinline__ int biased(const uint16_t *m, int i) { return (int)(int16_t)m[i]; }
+
 // ------------------------------------------------------------------------------------------------
 // demod_2400.c:109-172, the whole gate on one offset
 
@@ -81,8 +88,8 @@ __device__ __forceinline__ bool preamble_gate(const uint16_t *m, int e) {
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
             const uint32_t x = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh);
-            p[2 * i] = (int)(x & 0xffffu);
-            if (2 * i + 1 < 19) p[2 * i + 1] = (int)(x >> 16);
+            p[2 * i] = (int)(int16_t)(x & 0xffffu);  // biased samples: signed
+            if (2 * i + 1 < 19) p[2 * i + 1] = (int)x >> 16;
         }
     }
     const bool l0 = p[0] < p[1], g1 = p[1] > p[2], l2 = p[2] < p[3], g2 = p[2] > p[3], g3 = p[3] > p[4], l3 = p[3] < p[4],
@@ -93,16 +100,18 @@ __device__ __forceinline__ bool preamble_gate(const uint16_t *m, int e) {
     const bool c3 = g1 & l2 & g4 & l8 & g10 & l11;
     const bool c4 = g1 & l3 & g4 & l9 & g10 & l11;
     const bool c5 = g2 & l3 & g4 & l9 & g10 & l11;
-    const int h1 = p[1] + p[3] + p[9] + p[11] + p[12], s1 = p[1] + p[3] + p[9], n1 = p[5] + p[6] + p[7];
-    const int h2 = p[1] + p[3] + p[9] + p[12], s2 = h2, n2 = n1 + p[8];
-    const int h3 = p[1] + p[3] + p[4] + p[9] + p[10] + p[12], s3 = p[1] + p[12], n3 = p[6] + p[7];
-    const int h4 = p[1] + p[4] + p[10] + p[12], s4 = h4, n4 = n2;
-    const int h5 = p[1] + p[2] + p[4] + p[10] + p[12], s5 = p[4] + p[10] + p[12], n5 = p[6] + p[7] + p[8];
+    // sums of k magnitudes = sums of k biased samples + k * 32768
+    constexpr int B = (int)kBias;
+    const int h1 = p[1] + p[3] + p[9] + p[11] + p[12] + 5 * B, s1 = p[1] + p[3] + p[9] + 3 * B, n1 = p[5] + p[6] + p[7] + 3 * B;
+    const int h2 = p[1] + p[3] + p[9] + p[12] + 4 * B, s2 = h2, n2 = n1 + p[8] + B;
+    const int h3 = p[1] + p[3] + p[4] + p[9] + p[10] + p[12] + 6 * B, s3 = p[1] + p[12] + 2 * B, n3 = p[6] + p[7] + 2 * B;
+    const int h4 = p[1] + p[4] + p[10] + p[12] + 4 * B, s4 = h4, n4 = n2;
+    const int h5 = p[1] + p[2] + p[4] + p[10] + p[12] + 5 * B, s5 = p[4] + p[10] + p[12] + 3 * B, n5 = p[6] + p[7] + p[8] + 3 * B;
     const int hs = c1 ? h1 : c2 ? h2 : c3 ? h3 : c4 ? h4 : h5;
     const int sig = c1 ? s1 : c2 ? s2 : c3 ? s3 : c4 ? s4 : s5;
     const int noise = c1 ? n1 : c2 ? n2 : c3 ? n3 : c4 ? n4 : n5;
     const int high = hs / 4;
-    const int quiet = max(max(max(p[5], p[6]), max(p[7], p[8])), max(max(max(p[14], p[15]), max(p[16], p[17])), p[18]));
+    const int quiet = max(max(max(p[5], p[6]), max(p[7], p[8])), max(max(max(p[14], p[15]), max(p[16], p[17])), p[18])) + B;
     return l0 & g12 & (c1 | c2 | c3 | c4 | c5) & (sig * 2 >= 3 * noise) & (quiet < high);
 }
 
@@ -112,37 +121,36 @@ __device__ __forceinline__ bool preamble_gate(const uint16_t *m, int e) {
 
 template <int PH>
 __device__ __forceinline__ int corr(const uint16_t *m) {
-    const int a = m[0], b = m[1], c = m[2];
+    const int a = biased(m, 0), b = biased(m, 1), c = biased(m, 2);
     if constexpr (PH == 0) return 5 * a - 3 * b - 2 * c;
     if constexpr (PH == 1) return 4 * a - b - 3 * c;
     if constexpr (PH == 2) return 3 * a + b - 4 * c;
     if constexpr (PH == 3) return 2 * a + 3 * b - 5 * c;
-    return a + 5 * b - 5 * c - (int)m[3];
+    return a + 5 * b - 5 * c - biased(m, 3);
 }
 
-template <int PH>
-__device__ __forceinline__ int corrv(int a, int b, int c, int d) {
-    if constexpr (PH == 0) return 5 * a - 3 * b - 2 * c;
-    if constexpr (PH == 1) return 4 * a - b - 3 * c;
-    if constexpr (PH == 2) return 3 * a + b - 4 * c;
-    if constexpr (PH == 3) return 2 * a + 3 * b - 5 * c;
-    return a + 5 * b - 5 * c - d;
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, false);
 }
+constexpr uint32_t pk16(int lo, int hi) { return (uint32_t)(uint16_t)(int16_t)lo | ((uint32_t)(uint16_t)(int16_t)hi << 16); }
+using lds_dword = const __attribute__((address_space(3))) uint32_t;
 
-// Correlator PH at sample index e of the (4-byte aligned) magnitude array m, fetched as two or three
-// aligned dwords (one ds_read2_b32, plus one ds_read_b32 for the 4-tap correlator) instead of 3-4
-// 16-bit reads: the LDS pipe charges per instruction, not per byte.
+// MINUS correlator PH at the sample whose LDS byte address is A (even): two or three aligned dwords
+// (the LDS pipe charges per instruction, and unaligned ds_reads run ~20x slower), v_alignbyte to the
+// sample pairs, two dot products.  Negated so that "bit is 1" (correlator > 0) is the result's sign bit.
 template <int PH>
-__device__ __forceinline__ int corr_at(const uint16_t *m, int e) {
-    const uint32_t *q = (const uint32_t *)m + (e >> 1);
-    const uint32_t sh = (uint32_t)(e & 1) << 4;
+__device__ __forceinline__ int neg_corr_lds(uint32_t A) {
+    lds_dword *q = (lds_dword *)(uintptr_t)(A & ~3u);
     const uint32_t d0 = q[0], d1 = q[1];
-    const uint32_t x = __builtin_amdgcn_alignbit(d1, d0, sh);  // samples e, e+1
+    const uint32_t x = __builtin_amdgcn_alignbyte(d1, d0, A);  // samples e, e+1
     if constexpr (PH < 4) {
-        return corrv<PH>((int)(x & 0xffffu), (int)(x >> 16), (int)((d1 >> sh) & 0xffffu), 0);
+        const uint32_t t = __builtin_amdgcn_alignbyte(d1, d1, A);  // low half: sample e+2
+        constexpr int c[4][3] = {{5, -3, -2}, {4, -1, -3}, {3, 1, -4}, {2, 3, -5}};
+        return sdot2(x, pk16(-c[PH][0], -c[PH][1]), sdot2(t, pk16(-c[PH][2], 0), 0));
     } else {
-        const uint32_t y = __builtin_amdgcn_alignbit(q[2], d1, sh);  // samples e+2, e+3
-        return corrv<4>((int)(x & 0xffffu), (int)(x >> 16), (int)(y & 0xffffu), (int)(y >> 16));
+        const uint32_t y = __builtin_amdgcn_alignbyte(q[2], d1, A);  // samples e+2, e+3
+        return sdot2(x, pk16(-1, -5), sdot2(y, pk16(5, 1), 0));
     }
 }
 
@@ -211,23 +219,26 @@ constexpr RotTables make_rot_tables() {
 constexpr RotTables kRot = make_rot_tables();
 
 struct RotSlicer {
-    int off[5];       // sample offset (relative to the group base) at which correlator q is evaluated
-    uint32_t bit[5];  // the bit of the 5-bit group that correlator q decides (MSB = earliest bit)
+    uint32_t off2[5];  // byte offset (relative to the group base) of the sample at which correlator q is evaluated
+    uint32_t bit[5];   // the bit of the 5-bit group that correlator q decides (MSB = earliest bit)
     __device__ __forceinline__ explicit RotSlicer(uint32_t phase /* try_phase - 4 */) {
         const uint32_t o = phase == 0 ? kRot.off[0] : phase == 1 ? kRot.off[1] : phase == 2 ? kRot.off[2] : phase == 3 ? kRot.off[3] : kRot.off[4];
         const uint32_t b = phase == 0 ? kRot.bit[0] : phase == 1 ? kRot.bit[1] : phase == 2 ? kRot.bit[2] : phase == 3 ? kRot.bit[3] : kRot.bit[4];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            off[q] = (int)((o >> (4 * q)) & 15u);
+            off2[q] = ((o >> (4 * q)) & 15u) * 2;
             bit[q] = (b >> (5 * q)) & 31u;
         }
     }
-    // five bits starting at bit 5*G of the message; m = the strip's magnitudes, e = index of S[g + 19]
+    // five bits starting at bit 5*G of the message; m = biased magnitudes in LDS, e = index of S[g + 19]
     __device__ __forceinline__ uint32_t group(const uint16_t *m, int e, int G) const {
-        const int b = e + 12 * G;
-        const int c0 = corr_at<0>(m, b + off[0]), c1 = corr_at<1>(m, b + off[1]), c2 = corr_at<2>(m, b + off[2]),
-                  c3 = corr_at<3>(m, b + off[3]), c4 = corr_at<4>(m, b + off[4]);
-        return (c0 > 0 ? bit[0] : 0u) | (c1 > 0 ? bit[1] : 0u) | (c2 > 0 ? bit[2] : 0u) | (c3 > 0 ? bit[3] : 0u) | (c4 > 0 ? bit[4] : 0u);
+        const uint32_t A = (uint32_t)(uintptr_t)(m + e) + 24u * (uint32_t)G;
+        uint32_t r = (uint32_t)(neg_corr_lds<0>(A + off2[0]) >> 31) & bit[0];
+        r |= (uint32_t)(neg_corr_lds<1>(A + off2[1]) >> 31) & bit[1];
+        r |= (uint32_t)(neg_corr_lds<2>(A + off2[2]) >> 31) & bit[2];
+        r |= (uint32_t)(neg_corr_lds<3>(A + off2[3]) >> 31) & bit[3];
+        r |= (uint32_t)(neg_corr_lds<4>(A + off2[4]) >> 31) & bit[4];
+        return r;
     }
 };
 
@@ -344,6 +355,9 @@ __device__ void slow_item(const BatchArgs &a, const uint16_t *d, uint32_t g, int
 // its wavefront, so no workgroup barrier is ever executed: while one wavefront is in a stage that
 // keeps few lanes busy, the other wavefronts of the SIMD are in other stages.
 
+constexpr int kBloomWords = 512;
+__device__ __forceinline__ uint32_t bloom_bit(uint32_t syn) { return (syn * 0x85EBCA6Bu) >> 18; }  // 14 bits
+
 constexpr int kStrip = 2048;                      // scan offsets per strip
 constexpr int kStripVecs = (kStrip + kHalo) / 8;  // 16-byte vectors of 8 magnitudes per strip (294)
 constexpr int kScanWaves = 16;
@@ -351,7 +365,7 @@ constexpr int kScanThreads = 64 * kScanWaves;
 constexpr int kTileShift = 2;   // strips start at S index k*2048 - 2: then their first IQ sample, k*2048 - 328, is a multiple of 8
 constexpr int kEdgeCap = 704;   // edge-pattern candidates of half a strip (at most 2 of any 3 consecutive offsets can pass)
 constexpr int kGateCap = 192;   // gated offsets per strip that go through the dense stages; more take the per-thread path
-constexpr int kListCap = 320;   // short / long items per strip in the dense stages
+constexpr int kListCap = 256;   // short / long items per strip in the dense stages
 
 struct __attribute__((aligned(16))) WaveShared {
     uint16_t m[kStrip + kHalo];
@@ -363,7 +377,7 @@ static_assert(sizeof(WaveShared) % 16 == 0, "per-wave LDS regions must keep 16-b
 
 struct __attribute__((aligned(16))) ScanShared {
     uint16_t lut[16384];
-    uint32_t crcb[256];
+    uint32_t bloom[2][kBloomWords];  // one bit per hashed syndrome of the 56- / 112-bit repair table: most lookups end here
     uint32_t gsyn_long[23 * 32];   // per 5-bit group of a 112-bit frame: XOR of the single-bit syndromes of the set bits
     uint32_t gsyn_short[12 * 32];  // same for 56-bit frames
     WaveShared w[kScanWaves];
@@ -400,14 +414,14 @@ __device__ __forceinline__ uint32_t sc16_pair(uint4 v, int which) {
     const uint32_t a = which ? v.z : v.x, b = which ? v.w : v.y;
     const uint32_t m0 = float_mag((float)(short)(a & 0xffff) * scale, (float)(short)(a >> 16) * scale);
     const uint32_t m1 = float_mag((float)(short)(b & 0xffff) * scale, (float)(short)(b >> 16) * scale);
-    return m0 | (m1 << 16);
+    return (m0 | (m1 << 16)) ^ kBias2;
 }
 
 // Which branch of scoreModesMessage does a sliced frame take (mode_s.c:330-408)?  Works from the
 // pieces the group-parallel slicer reduces: DF + AA (the first 32 bits), the CRC syndrome, and
 // whether any message bit is set.  combo << 27 | value, or kDeadItem.
 template <bool LONG>
-__device__ uint32_t classify_fields(uint32_t w0, uint32_t syn, bool nonzero, const DeviceTables &t, uint32_t *adders) {
+__device__ uint32_t classify_fields(uint32_t w0, uint32_t syn, bool nonzero, const DeviceTables &t, uint32_t *adders, const uint32_t *bloom) {
     const uint32_t df = w0 >> 27, aa = w0 & 0xffffffu;
     if (!LONG) {
         if (!nonzero) return kDeadItem;                    // all-zero message, mode_s.c:325
@@ -415,6 +429,8 @@ __device__ uint32_t classify_fields(uint32_t w0, uint32_t syn, bool nonzero, con
         const uint32_t s = syn & 0xffff80u, iid = syn & 0x7fu;
         uint32_t info = 0;
         if (s) {
+            const uint32_t hb = bloom_bit(s);
+            if (!((bloom[hb >> 5] >> (hb & 31)) & 1u)) return kDeadItem;  // not in the table for sure
             info = diagnose(t, 0, s);
             if (info == kDeadItem || (info & 0xff) > 1) return kDeadItem;  // mode_s.c:350-358
         }
@@ -429,6 +445,8 @@ __device__ uint32_t classify_fields(uint32_t w0, uint32_t syn, bool nonzero, con
         if (df == 20 || df == 21) return (kComboCommB << 27) | syn;  // exact match or nothing (mode_s.c:391-403)
         uint32_t info = 0;  // DF17/18
         if (syn) {
+            const uint32_t hb = bloom_bit(syn);
+            if (!((bloom[hb >> 5] >> (hb & 31)) & 1u)) return kDeadItem;
             info = diagnose(t, 1, syn);
             if (info == kDeadItem) return kDeadItem;
         }
@@ -440,7 +458,7 @@ __device__ uint32_t classify_fields(uint32_t w0, uint32_t syn, bool nonzero, con
     }
 }
 
-// butterfly reductions inside 8 / 16 consecutive lanes with DPP moves (no LDS traffic)
+// butterfly reductions inside 4 / 8 / 16 consecutive lanes with DPP moves (no LDS traffic)
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
@@ -449,52 +467,52 @@ template <int SEG, typename OP>
 __device__ __forceinline__ uint32_t seg_reduce(uint32_t v, OP op) {
     v = op(v, dpp_mov<0xB1>(v));                 // quad_perm [1,0,3,2]
     v = op(v, dpp_mov<0x4E>(v));                 // quad_perm [2,3,0,1]
-    v = op(v, dpp_mov<0x141>(v));                // row_half_mirror: lane i <-> 7-i of each 8
+    if (SEG >= 8) v = op(v, dpp_mov<0x141>(v));  // row_half_mirror: lane i <-> 7-i of each 8
     if (SEG == 16) v = op(v, dpp_mov<0x140>(v)); // row_mirror: lane i <-> 15-i of each 16
     return v;
 }
 
-// Group-parallel slicing of one frame by SEG lanes (8 for 56-bit frames, 16 for 112-bit frames):
-// lane `sub` of the segment slices groups sub and sub + 12 (sub + 6 for short frames), five bits each, and looks up the XOR of
-// the syndromes of their set bits (the CRC is linear: crc.c:59-64,140; one 32-entry table per group);
-// the segment then reduces syndrome, first message word and a non-zero flag.  Straight-line code:
-// out-of-range groups are clamped and masked instead of branched around.
+// Group-parallel slicing of one frame by SEG lanes (4 for 56-bit frames, 8 for 112-bit frames): lane
+// `sub` of the segment slices the three 5-bit groups sub, sub + SEG and sub + 2 SEG (neighbouring lanes
+// then read LDS 24 bytes apart) and looks up the XOR of the syndromes of their set bits (the CRC is
+// linear: crc.c:59-64,140; one 32-entry table per group); the segment then reduces syndrome, first
+// message word and a non-zero flag.  Straight-line code: the one out-of-range group (23 of a long
+// frame) is clamped and masked instead of branched around.
+__device__ __forceinline__ uint32_t first_word_part(int G, uint32_t b) {  // where group G lands in message bits 0..31
+    return G < 6 ? (b << (27 - 5 * G)) : (G == 6 ? (b >> 3) : 0u);
+}
 template <bool LONG>
 __device__ __forceinline__ void slice_segment(const BatchArgs &a, const ScanShared &sh, const uint16_t *m, int e, uint32_t g, uint32_t phase,
                                               uint32_t sub, bool valid, ItemRec *region, uint32_t &nitems) {
-    constexpr int kGroups = LONG ? 23 : 12, kSeg = LONG ? 16 : 8;
+    constexpr int kSeg = LONG ? 8 : 4;
     const uint32_t *gsyn = LONG ? sh.gsyn_long : sh.gsyn_short;
     const RotSlicer rs(phase);
-    // lane sub slices groups sub and sub + SEG*3/4: neighbouring lanes then read LDS 24 bytes apart
-    // (distinct banks) instead of 48
-    constexpr int kHalf = LONG ? 12 : 6;
-    const int G0 = (int)sub, G1 = G0 + kHalf;
-    const bool v0 = valid && G0 < kHalf, v1 = valid && G0 < kHalf && G1 < kGroups;
-    const int H0 = v0 ? G0 : 0, H1 = v1 ? G1 : 0;
-    uint32_t b0 = 21, b1 = 10;
+    const int G0 = (int)sub, G1 = G0 + kSeg, G2 = G0 + 2 * kSeg;
+    const bool v2 = !LONG || G2 < 23;
+    const int H2 = v2 ? G2 : 0;
+    uint32_t b0 = 21, b1 = 10, b2 = 5;
     if (!(a.debug_flags & 2)) {
-        b0 = rs.group(m, e, H0);
-        b1 = rs.group(m, e, H1);
+        b0 = rs.group(m, e, G0);
+        b1 = rs.group(m, e, G1);
+        b2 = rs.group(m, e, H2);
     }
-    if (!LONG) {  // groups 11 holds bits 55..59: only bit 55 belongs to the frame
-        b1 = (H1 == 11) ? (b1 & 16u) : b1;
+    if (!LONG) {  // group 11 holds bits 55..59: only bit 55 belongs to the frame
+        b2 = (G2 == 11) ? (b2 & 16u) : b2;
     } else {      // group 22 holds bits 110..114: only 110 and 111 belong to the frame
-        b1 = (H1 == 22) ? (b1 & 24u) : b1;
+        b2 = (G2 == 22) ? (b2 & 24u) : b2;
+        b2 = v2 ? b2 : 0u;
     }
-    b0 = v0 ? b0 : 0u;
-    b1 = v1 ? b1 : 0u;
-    uint32_t syn = gsyn[H0 * 32 + b0] ^ gsyn[H1 * 32 + b1];  // entry 0 of every group is 0
+    uint32_t syn = gsyn[G0 * 32 + b0] ^ gsyn[G1 * 32 + b1] ^ gsyn[H2 * 32 + b2];  // entry 0 of every group is 0
     // groups 0..6 make up message bits 0..34; keep the first 32 (DF + AA)
-    const uint64_t top = (H0 <= 6 ? ((uint64_t)b0 << (59 - 5 * H0)) : 0ull) | (H1 <= 6 ? ((uint64_t)b1 << (59 - 5 * H1)) : 0ull);
-    uint32_t w0 = (uint32_t)(top >> 32);
-    uint32_t nz = b0 | b1;
+    uint32_t w0 = first_word_part(G0, b0) | (LONG ? 0u : first_word_part(G1, b1));
+    uint32_t nz = b0 | b1 | b2;
     if (!(a.debug_flags & 4)) {
         syn = seg_reduce<kSeg>(syn, [](uint32_t x, uint32_t y) { return x ^ y; });
         w0 = seg_reduce<kSeg>(w0, [](uint32_t x, uint32_t y) { return x | y; });
-        nz = seg_reduce<kSeg>(nz, [](uint32_t x, uint32_t y) { return x | y; });
+        if (!LONG) nz = seg_reduce<kSeg>(nz, [](uint32_t x, uint32_t y) { return x | y; });  // only 56-bit frames are checked (mode_s.c:325)
     }
     uint32_t cls = kDeadItem;
-    if (valid && sub == 0 && !(a.debug_flags & 1)) cls = classify_fields<LONG>(w0, syn, nz != 0, a.tab, a.adder_bitmap);
+    if (valid && sub == 0 && !(a.debug_flags & 1)) cls = classify_fields<LONG>(w0, syn, nz != 0, a.tab, a.adder_bitmap, sh.bloom[LONG ? 1 : 0]);
     const uint64_t em = __ballot(cls != kDeadItem);
     if (cls != kDeadItem) {
         const uint32_t pos = nitems + lanes_below(em);
@@ -512,9 +530,9 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     if (FMT == kFmtUC8)
         for (uint32_t i = tid; i < 16384; i += kScanThreads) {
             const uint32_t ai = i & 127, aq = i >> 7;
-            sh.lut[i ^ ((aq & 31) << 1)] = a.tab.uc8_lut[((128 + aq) << 8) | (128 + ai)];
+            sh.lut[i ^ ((aq & 31) << 1)] = (uint16_t)(a.tab.uc8_lut[((128 + aq) << 8) | (128 + ai)] ^ kBias);
         }
-    if (tid < 256) sh.crcb[tid] = a.tab.crc_bytes[tid];
+    for (uint32_t i = tid; i < 2 * kBloomWords; i += kScanThreads) sh.bloom[0][i] = 0;
     for (uint32_t i = tid; i < 23 * 32 + 12 * 32; i += kScanThreads) {
         // crc.c:59-64: bit k of an n-bit frame has the syndrome of bit k + 112 - n of a 112-bit frame
         const bool lng = i < 23 * 32;
@@ -526,36 +544,75 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         }
         (lng ? sh.gsyn_long : sh.gsyn_short)[e] = x;
     }
-    __syncthreads();  // the only workgroup barrier
+    __syncthreads();
+    for (int which = 0; which < 2; ++which) {
+        const uint32_t *keys = a.tab.syn_keys[which];
+        if (!keys) continue;  // --no-fix: empty table, every non-zero syndrome is uncorrectable
+        for (uint32_t i = tid; i <= a.tab.syn_mask[which]; i += kScanThreads) {
+            const uint32_t k = keys[i];
+            if (k) atomicOr(&sh.bloom[which][bloom_bit(k) >> 5], 1u << (bloom_bit(k) & 31));
+        }
+    }
+    __syncthreads();  // the last workgroup barrier: from here on every wavefront works alone
 
     WaveShared &W = sh.w[wave];
     const uint32_t gwave = blockIdx.x * kScanWaves + wave;
     ItemRec *region = a.items + (size_t)gwave * a.item_region;
     uint32_t nitems = 0, gated_total = 0, slow_total = 0;  // wave-uniform
     const uint64_t nstrips = (a.n + kTileShift + kStrip - 1) / kStrip;
-    for (uint64_t strip = (uint64_t)blockIdx.x * kScanWaves + wave; strip < nstrips; strip += (uint64_t)gridDim.x * kScanWaves) {
+    // The raw IQ of a strip is fetched one strip ahead into registers (5 x 16 bytes per lane), so the HBM
+    // latency of strip k + 1 hides behind the gate / slicing stages of strip k.
+    constexpr int kVecTrips = (kStripVecs + 63) / 64;
+    constexpr bool kVecFmt = (FMT == kFmtUC8 || FMT == kFmtSC16 || FMT == kFmtSC16Q11);
+    constexpr int kRawVecs = (FMT == kFmtUC8) ? 1 : 2;  // 16-byte loads per 8 samples
+    uint4 pre[kVecTrips][kRawVecs];
+    auto vec_direct = [&](int64_t s0, int v) {  // can vector v of the strip at S index s0 be read as aligned raw IQ?
+        const int64_t q = s0 + 8 * v - (int64_t)kTrailing;
+        return kVecFmt && a.iq_aligned && v < kStripVecs && q >= 0 && q + 8 <= (int64_t)a.n;
+    };
+    auto prefetch = [&](uint64_t strip) {
+        const int64_t s0 = (int64_t)(strip * kStrip) - kTileShift;
+#pragma unroll
+        for (int t = 0; t < kVecTrips; ++t) {
+            const int v = (int)lane + 64 * t;
+            if (strip < nstrips && vec_direct(s0, v)) {
+                const int64_t q = s0 + 8 * v - (int64_t)kTrailing;
+                const uint4 *src = (const uint4 *)((const uint8_t *)a.iq + (FMT == kFmtUC8 ? 2 : 4) * q);
+#pragma unroll
+                for (int r = 0; r < kRawVecs; ++r) pre[t][r] = src[r];
+            }
+        }
+    };
+    const uint64_t strip_step = (uint64_t)gridDim.x * kScanWaves;
+    prefetch((uint64_t)blockIdx.x * kScanWaves + wave);
+    for (uint64_t strip = (uint64_t)blockIdx.x * kScanWaves + wave; strip < nstrips; strip += strip_step) {
         const int64_t s0 = (int64_t)(strip * kStrip) - kTileShift;  // S index of m[0]
         wave_sync();
 
         // ---- convert.c: strip + halo -> magnitudes in LDS
-        for (int v = lane; v < kStripVecs; v += 64) {
-            const int64_t s = s0 + 8 * v, q = s - (int64_t)kTrailing;
+#pragma unroll
+        for (int t = 0; t < kVecTrips; ++t) {
+            const int v = (int)lane + 64 * t;
+            if (v >= kStripVecs) continue;
             uint4 o;
-            if ((FMT == kFmtUC8) && a.iq_aligned && q >= 0 && q + 8 <= (int64_t)a.n) {
-                const uint4 x = *(const uint4 *)((const uint8_t *)a.iq + 2 * q);
-                o = make_uint4(uc8_pair(x.x, sh.lut), uc8_pair(x.y, sh.lut), uc8_pair(x.z, sh.lut), uc8_pair(x.w, sh.lut));
-            } else if ((FMT == kFmtSC16 || FMT == kFmtSC16Q11) && a.iq_aligned && q >= 0 && q + 8 <= (int64_t)a.n) {
-                const uint4 *src = (const uint4 *)((const uint8_t *)a.iq + 4 * q);
-                const uint4 x0 = src[0], x1 = src[1];
-                o = make_uint4(sc16_pair<FMT>(x0, 0), sc16_pair<FMT>(x0, 1), sc16_pair<FMT>(x1, 0), sc16_pair<FMT>(x1, 1));
+            if (vec_direct(s0, v)) {
+                if constexpr (FMT == kFmtUC8) {
+                    const uint4 x = pre[t][0];
+                    o = make_uint4(uc8_pair(x.x, sh.lut), uc8_pair(x.y, sh.lut), uc8_pair(x.z, sh.lut), uc8_pair(x.w, sh.lut));
+                } else if constexpr (kVecFmt) {
+                    const uint4 x0 = pre[t][0], x1 = pre[t][kRawVecs - 1];
+                    o = make_uint4(sc16_pair<FMT>(x0, 0), sc16_pair<FMT>(x0, 1), sc16_pair<FMT>(x1, 0), sc16_pair<FMT>(x1, 1));
+                }
             } else {
+                const int64_t s = s0 + 8 * v;
                 uint32_t e[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) e[k] = stream_mag<FMT>(a, s + k);
+                for (int k = 0; k < 8; ++k) e[k] = stream_mag<FMT>(a, s + k) ^ kBias;
                 o = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
             }
             ((uint4 *)W.m)[v] = o;
         }
+        prefetch(strip + strip_step);
         wave_sync();
         if (a.stage_limit < 2) continue;
 
@@ -565,7 +622,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             uint32_t neq = 0;
             for (int r = 0; r < 2; ++r) {
                 const int base = (h * 2 + r) * 512 + (int)lane * 8;
-                uint32_t w[22];
+                int w[22];  // biased samples: signed comparisons
                 const uint4 *src = (const uint4 *)&W.m[base];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -573,8 +630,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                     const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (q * 8 + e * 2 < 22) w[q * 8 + e * 2] = d[e] & 0xffff;
-                        if (q * 8 + e * 2 + 1 < 22) w[q * 8 + e * 2 + 1] = d[e] >> 16;
+                        if (q * 8 + e * 2 < 22) w[q * 8 + e * 2] = (int)(int16_t)(d[e] & 0xffffu);
+                        if (q * 8 + e * 2 + 1 < 22) w[q * 8 + e * 2 + 1] = (int)d[e] >> 16;
                     }
                 }
                 uint64_t L[21], G[21];  // L[j]: S[base+j] < S[base+j+1] per lane, G[j]: >
@@ -623,7 +680,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                     if (pos < (uint32_t)kGateCap) {
                         W.gq[pos] = (uint16_t)j;
                     } else {
-                        for (int p = 0; p < 5; ++p) slow_item(a, &W.m[j + 19], g, p, sh.crcb);
+                        for (int p = 0; p < 5; ++p) slow_item(a, &W.m[j + 19], g, p, a.tab.crc_bytes);
                     }
                 }
                 if (a.emit_dead) nitems += __popcll(pm);
@@ -657,7 +714,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                     if (pos < (uint32_t)kListCap) {
                         W.lst[k][pos] = (uint16_t)i;
                     } else {
-                        slow_item(a, &W.m[j + 19], (uint32_t)(s0 + j), (int)phase, sh.crcb);
+                        slow_item(a, &W.m[j + 19], (uint32_t)(s0 + j), (int)phase, a.tab.crc_bytes);
                     }
                 }
                 nlist[k] += __popcll(cm);
@@ -668,11 +725,11 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         wave_sync();
         if (a.stage_limit < 5) continue;
 
-        // ---- 56-bit frames: eight lanes per frame
+        // ---- 56-bit frames: four lanes per frame, sixteen frames per pass
         {
             const uint32_t ns = min(nlist[0], (uint32_t)kListCap);
-            for (uint32_t cb = 0; cb < ns; cb += 8) {
-                const uint32_t c = cb + (lane >> 3);
+            for (uint32_t cb = 0; cb < ns; cb += 16) {
+                const uint32_t c = cb + (lane >> 2);
                 const bool valid = c < ns;
                 uint32_t j = 0, phase = 0;
                 if (valid) {
@@ -680,15 +737,15 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                     phase = i - 5 * cand;
                     j = W.gq[cand];
                 }
-                slice_segment<false>(a, sh, W.m, (int)j + 19, (uint32_t)(s0 + j), phase, lane & 7, valid, region, nitems);
+                slice_segment<false>(a, sh, W.m, (int)j + 19, (uint32_t)(s0 + j), phase, lane & 3, valid, region, nitems);
             }
         }
         if (a.stage_limit < 6) continue;
-        // ---- 112-bit frames: sixteen lanes per frame
+        // ---- 112-bit frames: eight lanes per frame, eight frames per pass
         {
             const uint32_t nl = min(nlist[1], (uint32_t)kListCap);
-            for (uint32_t cb = 0; cb < nl; cb += 4) {
-                const uint32_t c = cb + (lane >> 4);
+            for (uint32_t cb = 0; cb < nl; cb += 8) {
+                const uint32_t c = cb + (lane >> 3);
                 const bool valid = c < nl;
                 uint32_t j = 0, phase = 0;
                 if (valid) {
@@ -696,7 +753,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                     phase = i - 5 * cand;
                     j = W.gq[cand];
                 }
-                slice_segment<true>(a, sh, W.m, (int)j + 19, (uint32_t)(s0 + j), phase, lane & 15, valid, region, nitems);
+                slice_segment<true>(a, sh, W.m, (int)j + 19, (uint32_t)(s0 + j), phase, lane & 7, valid, region, nitems);
             }
         }
     }
@@ -783,7 +840,7 @@ __global__ __launch_bounds__(64) void k_finalize(const BatchArgs a) {
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = blockIdx.x; i < nsurv; i += gridDim.x) {
         const uint32_t g = a.surv_g[i];
-        for (uint32_t k = lane; k < (uint32_t)kHalo; k += 64) m[k] = (uint16_t)stream_mag<FMT>(a, (int64_t)g + k);
+        for (uint32_t k = lane; k < (uint32_t)kHalo; k += 64) m[k] = (uint16_t)(stream_mag<FMT>(a, (int64_t)g + k) ^ kBias);
         __syncthreads();
         Survivor *out = &a.survivors[i];
         if (lane < 5) {
@@ -795,7 +852,7 @@ __global__ __launch_bounds__(64) void k_finalize(const BatchArgs a) {
         // demod_2400.c:345-351 for both possible frame lengths
         uint64_t p134 = 0, p268 = 0;
         for (uint32_t k = lane; k < 268; k += 64) {
-            const uint64_t v = (uint64_t)m[19 + k] * m[19 + k];
+            const uint64_t mag = m[19 + k] ^ kBias, v = mag * mag;
             p268 += v;
             if (k < 134) p134 += v;
         }
@@ -980,7 +1037,7 @@ __global__ __launch_bounds__(kThreads) void k_replay_emit(const BatchArgs a, con
         const bool lng = !combo_is_short(combo);
         const uint32_t nbits = lng ? 112 : 56, ngroups = lng ? 23 : 12;
         wave_sync();
-        for (uint32_t k = lane; k < (uint32_t)kHalo; k += 64) win[wave][k] = (uint16_t)stream_mag<FMT>(a, (int64_t)g + k);
+        for (uint32_t k = lane; k < (uint32_t)kHalo; k += 64) win[wave][k] = (uint16_t)(stream_mag<FMT>(a, (int64_t)g + k) ^ kBias);
         wave_sync();
         uint32_t b = 0, syn = 0;
         if (lane < ngroups) {
@@ -997,7 +1054,10 @@ __global__ __launch_bounds__(kThreads) void k_replay_emit(const BatchArgs a, con
         // demod_2400.c:345-351
         const uint32_t signal_len = nbits * 12 / 5;
         uint64_t pw = 0;
-        for (uint32_t k = lane; k < signal_len; k += 64) pw += (uint64_t)win[wave][19 + k] * win[wave][19 + k];
+        for (uint32_t k = lane; k < signal_len; k += 64) {
+            const uint64_t mag = win[wave][19 + k] ^ kBias;
+            pw += mag * mag;
+        }
         for (int off = 32; off > 0; off >>= 1) {
             syn ^= __shfl_xor(syn, off, 64);
             pw += __shfl_xor(pw, off, 64);
