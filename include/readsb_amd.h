@@ -159,7 +159,8 @@ const char *rsb_version(void);
 /* ---- stand-alone pieces of the path, for callers that bind them one by one -------------- */
 
 /* iq_convert_fn on device buffers (convert.c:63-423): nsamples IQ -> uint16 magnitudes.
- * mean_level / mean_power may be NULL (convert.c:104-110). UC8 no-DC only returns exact means. */
+ * mean_level / mean_power may be NULL; they are the reference's, bit for bit: integer sums for UC8
+ * (convert.c:104-110), float32 running sums taken in sample order for SC16 / SC16Q11 (:254-260). */
 int rsb_convert_device(rsb_ctx *ctx, const void *iq_dev, void *mag_dev, uint64_t nsamples, void *stream,
                        double *mean_level, double *mean_power);
 

@@ -93,6 +93,7 @@ int setup_device(rsb_ctx *c) {
     HIP_TRY(c, hipMalloc((void **)&c->d_bitmap, (1u << 24) / 8));
     HIP_TRY(c, hipMalloc((void **)&c->d_counters, kCntCount * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_block_sums, c->nblocks_cap * 2 * sizeof(uint64_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_block_means, c->nblocks_cap * 2 * sizeof(double)));
     HIP_TRY(c, hipMalloc(&c->d_carry, kTrailing * 4));
     c->host_replay_only = (c->cfg.flags & RSB_FLAG_HOST_REPLAY) != 0;
     if (!c->host_replay_only) {
@@ -219,10 +220,6 @@ int rsb_create(const rsb_config *cfg, rsb_ctx **out) {
         return RSB_EINVAL;
     }
     if (cfg->fix_bits < 0 || cfg->max_batch_samples == 0 || cfg->max_batch_samples > 0xfffff000ull) return RSB_EINVAL;
-    if (cfg->mode_ac && cfg->input_format != RSB_UC8) {
-        std::fprintf(stderr, "readsb_amd: --modeac needs the integer block statistics of the UC8 converter\n");
-        return RSB_EINVAL;
-    }
     rsb_ctx *c = new (std::nothrow) rsb_ctx(*cfg);
     if (!c) return RSB_ENOMEM;
     int rc = setup_device(c);
@@ -241,7 +238,7 @@ void rsb_destroy(rsb_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1],
                     c->d_items, c->d_region_counts, c->d_skeys[0], c->d_skeys[1], c->d_sinfo[0], c->d_sinfo[1], c->d_sort_temp, c->d_surv_g, c->d_surv, c->d_ac, c->d_bitmap, c->d_counters, c->d_block_sums, c->d_carry,
-                    c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_new_adders, c->d_addr_upload};
+                    c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_new_adders, c->d_addr_upload, c->d_means, c->d_block_means};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t ev : c->ev)
@@ -281,8 +278,35 @@ int rsb_filter_expire(rsb_ctx *c) {
     return RSB_OK;
 }
 
+static int enqueue_batch(rsb_ctx *c, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCntCount * sizeof(uint32_t), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_region_counts, 0, (size_t)a.n_regions * sizeof(uint32_t), s));
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    if (c->run_modes) HIP_TRY(c, launch_scan(a, c->scan_grid, s));
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    if (c->run_modes) HIP_TRY(c, launch_prune(a, s));
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    if (c->run_ac && nsamples) {
+        const size_t nblk = (nsamples + kBlock - 1) / kBlock;
+        BatchArgs ac = a;
+        if (!ac.block_means && a.fmt != kFmtUC8) {
+            // the float converters' block means (convert.c:226-262): exact only in sample order
+            HIP_TRY(c, launch_block_means_float(a.fmt, a.iq, nsamples, kBlock, c->d_block_means, s));
+            ac.block_means = c->d_block_means;
+        }
+        if (!ac.block_means) HIP_TRY(c, hipMemsetAsync(c->d_block_sums, 0, nblk * 2 * sizeof(uint64_t), s));
+        HIP_TRY(c, launch_modeac(ac, s));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    c->pending = true;
+    c->pending_n = nsamples;
+    c->pending_stream = s;
+    c->pending_args = a;
+    return RSB_OK;
+}
+
 int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) {
-    if (!c || (!iq_dev && nsamples)) return RSB_EINVAL;
+    if (!c || (!iq_dev && nsamples) || c->block_mode) return RSB_EINVAL;
     if (c->pending) {
         c->err = "rsb_submit: previous batch not collected";
         return RSB_ESTATE;
@@ -295,27 +319,8 @@ int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) 
         c->err = "rsb_submit: nsamples exceeds rsb_config.max_batch_samples";
         return RSB_EINVAL;
     }
-    hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    BatchArgs a = c->batch_args(iq_dev, nsamples, c->cfg.input_format);
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCntCount * sizeof(uint32_t), s));
-    HIP_TRY(c, hipMemsetAsync(c->d_region_counts, 0, (size_t)a.n_regions * sizeof(uint32_t), s));
-    HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    HIP_TRY(c, launch_scan(a, c->scan_grid, s));
-    HIP_TRY(c, hipEventRecord(c->ev[1], s));
-    HIP_TRY(c, launch_prune(a, s));
-    HIP_TRY(c, hipEventRecord(c->ev[2], s));
-    if (c->cfg.mode_ac && nsamples) {
-        const size_t nblk = (nsamples + kBlock - 1) / kBlock;
-        HIP_TRY(c, hipMemsetAsync(c->d_block_sums, 0, nblk * 2 * sizeof(uint64_t), s));
-        HIP_TRY(c, launch_modeac(a, s));
-    }
-    HIP_TRY(c, hipEventRecord(c->ev[3], s));
-    c->pending = true;
-    c->pending_n = nsamples;
-    c->pending_stream = s;
-    c->pending_args = a;
-    return RSB_OK;
+    return enqueue_batch(c, c->batch_args(iq_dev, nsamples, c->cfg.input_format), nsamples, (hipStream_t)stream);
 }
 
 int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
@@ -350,7 +355,11 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     c->h_blk_counts.resize(nblocks + 1);
     int on_device = 0;
     c->timing.replay_iterations = 0;
-    if (!c->host_replay_only && !a.emit_dead && !a.keep_all) {
+    if (!c->run_modes) {
+        on_device = 1;  // nothing to replay: a Mode A/C only pass of the drop-in
+        std::memset(cnt + kCntChanged, 0, (kCntCount - kCntChanged) * sizeof(uint32_t));
+        c->h_blk_counts.assign(nblocks + 1, 0);
+    } else if (!c->host_replay_only && !a.emit_dead && !a.keep_all) {
         on_device = device_replay(c, n_items, s, cnt);
         if (on_device < 0) return on_device;
     }
@@ -361,7 +370,7 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
         HIP_TRY(c, hipMemcpyAsync(&nsurv, c->d_counters + kCntSurvivors, sizeof(nsurv), hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
-    if (c->pending_n % kBlock == 0 && c->pending_n) {
+    if (!c->block_mode && c->pending_n % kBlock == 0 && c->pending_n) {
         // the next batch's 326-sample overlap (sdr_ifile.c:199-201); only now, the kernels above still read the old one
         const unsigned bps = (c->cfg.input_format == RSB_UC8) ? 2 : 4;
         HIP_TRY(c, hipMemcpyAsync(c->d_carry, (const char *)a.iq + (c->pending_n - kTrailing) * bps, (size_t)kTrailing * bps, hipMemcpyDeviceToDevice, s));
@@ -443,9 +452,11 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     st.survivors += on_device ? cnt[kCntAccepted] : cnt[kCntSurvivors];
     st.modeac_candidates += cnt[kCntAc];
 
-    c->stream_pos += c->pending_n;
-    if (c->pending_n % kBlock != 0) c->finished = true;
-    if (c->pending_n % kBlock == 0 && c->pending_n) c->carry_valid = 1;
+    if (!c->block_mode) {
+        c->stream_pos += c->pending_n;
+        if (c->pending_n % kBlock != 0) c->finished = true;
+        if (c->pending_n % kBlock == 0 && c->pending_n) c->carry_valid = 1;
+    }
 
     if (n_out) *n_out = n;
     if (!delivered) {
@@ -501,16 +512,24 @@ int rsb_convert_device(rsb_ctx *c, const void *iq_dev, void *mag_dev, uint64_t n
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const bool want = mean_level || mean_power;
+    const bool float_path = c->cfg.input_format != RSB_UC8;
     if (want && !c->d_sums) HIP_TRY(c, hipMalloc((void **)&c->d_sums, 2 * sizeof(uint64_t)));
-    if (want) HIP_TRY(c, hipMemsetAsync(c->d_sums, 0, 2 * sizeof(uint64_t), s));
-    HIP_TRY(c, launch_convert(c->cfg.input_format, iq_dev, (uint16_t *)mag_dev, nsamples, c->d_lut, want ? c->d_sums : nullptr, s));
+    if (want && !float_path) HIP_TRY(c, hipMemsetAsync(c->d_sums, 0, 2 * sizeof(uint64_t), s));
+    HIP_TRY(c, launch_convert(c->cfg.input_format, iq_dev, (uint16_t *)mag_dev, nsamples, c->d_lut, (want && !float_path) ? c->d_sums : nullptr, s));
+    if (want && float_path) HIP_TRY(c, launch_block_means_float(c->cfg.input_format, iq_dev, nsamples, nsamples, (double *)c->d_sums, s));
     if (want) {
         uint64_t sums[2];
         HIP_TRY(c, hipMemcpyAsync(sums, c->d_sums, sizeof(sums), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
-        // convert.c:104-110 (integer converters; the float converters' sequential float32 sums are not reproduced here)
-        if (mean_level) *mean_level = sums[0] / 65536.0 / (unsigned)nsamples;
-        if (mean_power) *mean_power = sums[1] / 65535.0 / 65535.0 / (unsigned)nsamples;
+        if (float_path) {  // convert.c:254-260 / :371-377
+            double means[2];
+            std::memcpy(means, sums, sizeof(means));
+            if (mean_level) *mean_level = means[0];
+            if (mean_power) *mean_power = means[1];
+        } else {  // convert.c:104-110
+            if (mean_level) *mean_level = sums[0] / 65536.0 / (unsigned)nsamples;
+            if (mean_power) *mean_power = sums[1] / 65535.0 / 65535.0 / (unsigned)nsamples;
+        }
     }
     return RSB_OK;
 }
@@ -570,3 +589,42 @@ int rsb_host_replay(int fix_bits, uint64_t g0, const rsb_candidate *cands, size_
 }
 
 }  // extern "C"
+
+// ---- behind include/readsb_dropin.h ------------------------------------------------------------------
+
+int rsb_internal_create_block_ctx(int fix_bits, int device, unsigned max_length, rsb_ctx **out) {
+    rsb_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    cfg.input_format = RSB_UC8;  // placeholder: block contexts are fed magnitudes
+    cfg.fix_bits = fix_bits;
+    cfg.mode_ac = 1;
+    cfg.device = device;
+    cfg.queue_div = 8;
+    cfg.max_batch_samples = max_length ? max_length : kBlock;
+    const int rc = rsb_create(&cfg, out);
+    if (rc != RSB_OK) return rc;
+    rsb_ctx *c = *out;
+    c->block_mode = true;
+    if (hipMalloc((void **)&c->d_means, 2 * sizeof(double)) != hipSuccess) {
+        rsb_destroy(c);
+        *out = nullptr;
+        return RSB_ENOMEM;
+    }
+    return RSB_OK;
+}
+
+int rsb_internal_submit_block(rsb_ctx *c, const uint16_t *mag_dev, unsigned length, bool modes, bool modeac, double mean_level, double mean_power) {
+    if (!c || !c->block_mode || !mag_dev || length > c->cfg.max_batch_samples) return RSB_EINVAL;
+    if (c->pending) return RSB_ESTATE;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    c->run_modes = modes;
+    c->run_ac = modeac;
+    BatchArgs a = c->batch_args(mag_dev + kTrailing, length, kFmtMag16, mag_dev);
+    a.iq_aligned = 0;  // magnitudes go through the per-sample path of the scan kernel
+    if (modeac) {
+        const double means[2] = {mean_level, mean_power};
+        HIP_TRY(c, hipMemcpy(c->d_means, means, sizeof(means), hipMemcpyHostToDevice));
+        a.block_means = c->d_means;
+    }
+    return enqueue_batch(c, a, length, nullptr);
+}

@@ -12,6 +12,7 @@
 
 struct rsb_ctx {
     explicit rsb_ctx(const rsb_config &c) : cfg(c), replay(c.fix_bits) {
+        run_ac = c.mode_ac != 0;
         std::memset(&timing, 0, sizeof(timing));
         for (hipEvent_t &e : ev) e = nullptr;
     }
@@ -45,6 +46,7 @@ struct rsb_ctx {
     uint32_t *d_bitmap = nullptr;
     uint32_t *d_counters = nullptr;
     uint64_t *d_block_sums = nullptr;
+    double *d_block_means = nullptr;  // SC16 / SC16Q11 with Mode A/C: the float converters' per-block means
     size_t nblocks_cap = 0;
     void *d_carry = nullptr;
     void *d_stage = nullptr;
@@ -64,6 +66,11 @@ struct rsb_ctx {
     std::vector<uint2> h_new_adders;
     uint64_t *d_sums = nullptr;
 
+    // drop-in block mode (dropin.cpp): every call is one struct mag_buf -- magnitudes in, overlap included
+    bool block_mode = false;
+    bool run_modes = true, run_ac = false;
+    double *d_means = nullptr;
+
     // stream state
     uint64_t stream_pos = 0;
     int carry_valid = 0;
@@ -79,12 +86,12 @@ struct rsb_ctx {
     std::vector<rsb::AcCand> h_ac;
     std::vector<rsb_message> msgs, dev_msgs;
 
-    rsb::BatchArgs batch_args(const void *iq, uint64_t n, int fmt) const {
+    rsb::BatchArgs batch_args(const void *iq, uint64_t n, int fmt, const void *carry = nullptr) const {
         rsb::BatchArgs a;
         std::memset(&a, 0, sizeof(a));
         a.iq = iq;
-        a.carry = d_carry;
-        a.carry_valid = carry_valid;
+        a.carry = carry ? carry : d_carry;
+        a.carry_valid = carry ? 1 : carry_valid;
         a.fmt = fmt;
         a.n = n;
         a.tab.uc8_lut = d_lut;
@@ -120,6 +127,7 @@ struct rsb_ctx {
         a.adder_bitmap = d_bitmap;
         a.counters = d_counters;
         a.block_sums = d_block_sums;
+        a.block_means = nullptr;
         a.emit_dead = 0;
         a.keep_all = 0;
         a.stage_limit = stage_limit;
@@ -127,3 +135,8 @@ struct rsb_ctx {
         return a;
     }
 };
+
+// internal entry points behind include/readsb_dropin.h (dropin.cpp)
+int rsb_internal_create_block_ctx(int fix_bits, int device, unsigned max_length, rsb_ctx **out);
+// one struct mag_buf: mag_dev = 326 overlap samples + length samples, already on the device
+int rsb_internal_submit_block(rsb_ctx *c, const uint16_t *mag_dev, unsigned length, bool modes, bool modeac, double mean_level, double mean_power);

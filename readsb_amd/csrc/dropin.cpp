@@ -1,0 +1,240 @@
+// dropin.cpp -- include/readsb_dropin.h: the reference's per-block entry points on top of the kernels.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/readsb_dropin.h"
+#include "ctx.hpp"
+
+using namespace rsb;
+
+// ================================================================================== convert.h
+
+struct rsbd_converter_state {
+    int format;
+    int device;
+    rsb_ctx *ctx;  // owns the tables (UC8 LUT) and the sums buffer
+    void *d_iq = nullptr;
+    uint16_t *d_mag = nullptr;
+    size_t cap = 0;  // samples
+};
+
+namespace {
+
+void convert_entry(void *iq_data, uint16_t *mag_data, unsigned nsamples, rsbd_converter_state *st, double *out_mean_level, double *out_mean_power) {
+    // convert.c:63-423: nsamples IQ pairs in, nsamples magnitudes out, optional block means
+    if (!st || !iq_data || !mag_data || nsamples == 0) {
+        // convert.c:104-110 divides by nsamples; the reference is never called with 0
+        if (out_mean_level) *out_mean_level = 0;
+        if (out_mean_power) *out_mean_power = 0;
+        return;
+    }
+    if (hipSetDevice(st->device) != hipSuccess) return;
+    const unsigned bps = st->format == RSB_UC8 ? 2 : 4;
+    if (nsamples > st->cap) {
+        if (st->d_iq) (void)hipFree(st->d_iq);
+        if (st->d_mag) (void)hipFree(st->d_mag);
+        st->d_iq = nullptr;
+        st->d_mag = nullptr;
+        st->cap = 0;
+        if (hipMalloc(&st->d_iq, (size_t)nsamples * bps) != hipSuccess || hipMalloc((void **)&st->d_mag, (size_t)nsamples * 2) != hipSuccess) {
+            std::fprintf(stderr, "readsb_amd: converter: device allocation of %u samples failed\n", nsamples);
+            return;
+        }
+        st->cap = nsamples;
+    }
+    if (hipMemcpy(st->d_iq, iq_data, (size_t)nsamples * bps, hipMemcpyHostToDevice) != hipSuccess) return;
+    double lvl = 0, pwr = 0;
+    const bool want = out_mean_level || out_mean_power;
+    if (rsb_convert_device(st->ctx, st->d_iq, st->d_mag, nsamples, nullptr, want ? &lvl : nullptr, want ? &pwr : nullptr) != RSB_OK) {
+        std::fprintf(stderr, "readsb_amd: converter: %s\n", rsb_last_error(st->ctx));
+        return;
+    }
+    if (hipMemcpy(mag_data, st->d_mag, (size_t)nsamples * 2, hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (out_mean_level) *out_mean_level = lvl;
+    if (out_mean_power) *out_mean_power = pwr;
+}
+
+}  // namespace
+
+extern "C" rsbd_iq_convert_fn rsbd_init_converter(int format, double /*sample_rate: only the DC filter uses it (convert.c:480-488)*/, int filter_dc,
+                                                  rsbd_converter_state **out_state) {
+    if (out_state) *out_state = nullptr;
+    if (format < RSB_UC8 || format > RSB_SC16Q11 || filter_dc || !out_state) {
+        std::fprintf(stderr, "no suitable converter for format=%d dc=%d\n", format, filter_dc);  // convert.c:460-464
+        return nullptr;
+    }
+    rsb_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    cfg.input_format = format;
+    cfg.fix_bits = 0;
+    cfg.max_batch_samples = 4096;  // the context is used for its tables only
+    cfg.flags = RSB_FLAG_HOST_REPLAY;
+    rsb_ctx *ctx = nullptr;
+    if (rsb_create(&cfg, &ctx) != RSB_OK) return nullptr;  // message already printed
+    rsbd_converter_state *st = new (std::nothrow) rsbd_converter_state;
+    if (!st) {
+        rsb_destroy(ctx);
+        return nullptr;
+    }
+    st->format = format;
+    st->device = 0;
+    st->ctx = ctx;
+    *out_state = st;
+    return convert_entry;
+}
+
+extern "C" void rsbd_cleanup_converter(rsbd_converter_state *st) {
+    if (!st) return;
+    (void)hipSetDevice(st->device);
+    if (st->d_iq) (void)hipFree(st->d_iq);
+    if (st->d_mag) (void)hipFree(st->d_mag);
+    rsb_destroy(st->ctx);
+    delete st;
+}
+
+// ================================================================================== crc.h
+
+namespace {
+
+struct CrcGlobals {  // the statics of crc.c
+    std::mutex mu;
+    CrcTables *tables = nullptr;
+    std::vector<rsbd_errorinfo> short_, long_;
+    rsbd_errorinfo no_errors = {0, 0, {0, 0}};  // crc.c:28
+};
+CrcGlobals &crc_globals() {
+    static CrcGlobals g;
+    return g;
+}
+
+void fill(std::vector<rsbd_errorinfo> &dst, const std::vector<SyndromeEntry> &src) {
+    dst.clear();
+    for (const SyndromeEntry &e : src) dst.push_back(rsbd_errorinfo{e.syndrome, e.errors, {e.bit[0], e.bit[1]}});
+}
+
+}  // namespace
+
+extern "C" void rsbd_modesChecksumInit(int fixBits) {
+    CrcGlobals &g = crc_globals();
+    std::lock_guard<std::mutex> lock(g.mu);
+    delete g.tables;
+    g.tables = new CrcTables(fixBits);
+    fill(g.short_, g.tables->table(56));
+    fill(g.long_, g.tables->table(112));
+}
+
+extern "C" uint32_t rsbd_modesChecksum(uint8_t *msg, int bitlen) {
+    if (!msg || (bitlen != 56 && bitlen != 112)) return 0xffffffffu;  // the reference asserts (crc.c:72-73)
+    return CrcTables::checksum(msg, bitlen);
+}
+
+extern "C" rsbd_errorinfo *rsbd_modesChecksumDiagnose(uint32_t syndrome, int bitlen) {
+    CrcGlobals &g = crc_globals();
+    if (syndrome == 0) return &g.no_errors;  // crc.c:389-390
+    if (!g.tables || (bitlen != 56 && bitlen != 112)) return nullptr;
+    const SyndromeEntry *e = g.tables->diagnose(syndrome, bitlen);
+    if (!e) return nullptr;
+    const std::vector<SyndromeEntry> &t = g.tables->table(bitlen);
+    std::vector<rsbd_errorinfo> &mine = bitlen == 56 ? g.short_ : g.long_;
+    return &mine[(size_t)(e - t.data())];
+}
+
+extern "C" void rsbd_modesChecksumFix(uint8_t *msg, rsbd_errorinfo *info) {
+    if (!info || !msg) return;  // crc.c:413-414
+    for (int i = 0; i < info->errors; ++i) msg[info->bit[i] >> 3] ^= uint8_t(1u << (7 - (info->bit[i] & 7)));
+}
+
+extern "C" void rsbd_crcCleanupTables(void) {
+    CrcGlobals &g = crc_globals();
+    std::lock_guard<std::mutex> lock(g.mu);
+    delete g.tables;
+    g.tables = nullptr;
+    g.short_.clear();
+    g.long_.clear();
+}
+
+// ================================================================================== demod_2400.h
+
+struct rsbd_modes {
+    rsb_ctx *ctx = nullptr;
+    uint16_t *d_mag = nullptr;
+    unsigned max_length = 0;
+    std::vector<rsb_message> out;
+};
+
+extern "C" rsbd_modes *rsbd_modesInit(int nfix_crc, int device, unsigned max_length) {
+    if (max_length == 0) max_length = kBlock;
+    if (max_length > kBlock) {
+        std::fprintf(stderr, "readsb_amd: mag_buf.length above MODES_MAG_BUF_SAMPLES (%u) is not supported\n", kBlock);
+        return nullptr;
+    }
+    rsbd_modes *m = new (std::nothrow) rsbd_modes;
+    if (!m) return nullptr;
+    if (rsb_internal_create_block_ctx(nfix_crc, device, max_length, &m->ctx) != RSB_OK ||
+        hipMalloc((void **)&m->d_mag, ((size_t)max_length + kTrailing) * sizeof(uint16_t)) != hipSuccess) {
+        std::fprintf(stderr, "readsb_amd: cannot set up the demodulator on HIP device %d (there is no CPU fallback)\n", device);
+        if (m->ctx) rsb_destroy(m->ctx);
+        delete m;
+        return nullptr;
+    }
+    m->max_length = max_length;
+    m->out.resize(max_length / 64 + 64);
+    return m;
+}
+
+extern "C" void rsbd_modesCleanup(rsbd_modes *m) {
+    if (!m) return;
+    if (m->d_mag) (void)hipFree(m->d_mag);
+    rsb_destroy(m->ctx);
+    delete m;
+}
+
+extern "C" void rsbd_icaoFilterInit(rsbd_modes *m) {
+    if (m) (void)rsb_reset(m->ctx);
+}
+extern "C" void rsbd_icaoFilterAdd(rsbd_modes *m, uint32_t addr) {
+    if (m) (void)rsb_filter_add(m->ctx, addr);
+}
+extern "C" void rsbd_icaoFilterExpire(rsbd_modes *m) {
+    if (m) (void)rsb_filter_expire(m->ctx);
+}
+
+namespace {
+
+void run_block(rsbd_modes *m, rsbd_mag_buf *mag, bool modes, bool modeac, rsbd_use_message_fn use, void *user) {
+    if (!m || !mag || !mag->data) return;
+    if (mag->length > m->max_length) {
+        std::fprintf(stderr, "readsb_amd: mag_buf.length %u exceeds the %u given to rsbd_modesInit: block dropped\n", mag->length, m->max_length);
+        return;
+    }
+    if (hipMemcpy(m->d_mag, mag->data, ((size_t)mag->length + kTrailing) * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) return;
+    size_t n = 0;
+    int rc = rsb_internal_submit_block(m->ctx, m->d_mag, mag->length, modes, modeac, mag->mean_level, mag->mean_power);
+    if (rc == RSB_OK) {
+        rc = rsb_collect(m->ctx, m->out.data(), m->out.size(), &n);
+        if (rc == RSB_EOVERFLOW && n > m->out.size()) {
+            std::fprintf(stderr, "readsb_amd: %zu messages in one block exceed the %zu provided for; the rest is dropped\n", n, m->out.size());
+            n = m->out.size();
+            rc = RSB_OK;
+        }
+    }
+    if (rc != RSB_OK) {
+        std::fprintf(stderr, "readsb_amd: demodulator: %s\n", rsb_last_error(m->ctx));
+        return;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        rsb_message &mm = m->out[i];
+        mm.timestamp += mag->sampleTimestamp;  // demod_2400.c:320 / :649 are relative to the block's own clock
+        if (use) use(user, &mm);
+    }
+}
+
+}  // namespace
+
+extern "C" void rsbd_demodulate2400(rsbd_modes *m, rsbd_mag_buf *mag, rsbd_use_message_fn use, void *user) { run_block(m, mag, true, false, use, user); }
+extern "C" void rsbd_demodulate2400AC(rsbd_modes *m, rsbd_mag_buf *mag, rsbd_use_message_fn use, void *user) { run_block(m, mag, false, true, use, user); }

@@ -1141,6 +1141,46 @@ __global__ __launch_bounds__(kThreads) void k_block_sums(const BatchArgs a) {
     }
 }
 
+// convert.c:226-262 / :343-379: the float converters accumulate float32 sums sample by sample, and float
+// addition does not reassociate.  One wavefront per block: 64 lanes compute 64 samples' mag / magsq at
+// a time, then the two running sums take them in sample order (v_readlane + v_add, the only serial part).
+template <int FMT>
+__global__ __launch_bounds__(64) void k_block_means_float(const void *iq, uint64_t n, uint64_t blk_len, double *means) {
+    if constexpr (FMT == kFmtSC16 || FMT == kFmtSC16Q11) {
+        const uint64_t start = (uint64_t)blockIdx.x * blk_len;
+        const uint32_t len = (uint32_t)((n - start < blk_len) ? (n - start) : blk_len), lane = threadIdx.x;
+        constexpr float scale = (FMT == kFmtSC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+        float sum_level = 0, sum_power = 0;
+        for (uint32_t base = 0; base < len; base += 64) {
+            float mag = 0, magsq = 0;
+            if (base + lane < len) {
+                const short2 v = ((const short2 *)iq)[start + base + lane];
+                const float fI = (float)v.x * scale, fQ = (float)v.y * scale;
+                magsq = fI * fI + fQ * fQ;
+                if (magsq > 1.0f) magsq = 1.0f;
+                mag = sqrtf(magsq);
+            }
+            const uint32_t cnt = (len - base < 64u) ? (len - base) : 64u;
+            if (cnt == 64) {
+#pragma unroll
+                for (int k = 0; k < 64; ++k) {
+                    sum_power += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, magsq), k));
+                    sum_level += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mag), k));
+                }
+            } else {
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    sum_power += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, magsq), (int)k));
+                    sum_level += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mag), (int)k));
+                }
+            }
+        }
+        if (lane == 0) {  // "sum / nsamples" is a float division there (float / unsigned), widened afterwards
+            means[2 * blockIdx.x] = (double)(sum_level / (float)len);
+            means[2 * blockIdx.x + 1] = (double)(sum_power / (float)len);
+        }
+    }
+}
+
 constexpr int kAcBack = 1;    // m[f1_sample - 1]
 constexpr int kAcAhead = 72;  // bit 19 is sliced at f1_sample + 67 and looks 2 further (demod_2400.c:587-608)
 
@@ -1159,8 +1199,8 @@ __global__ __launch_bounds__(kThreads) void k_modeac(const BatchArgs a) {
     const uint64_t blk_start = blk * kBlock;
     const uint64_t blk_len = (a.n - blk_start < (uint64_t)kBlock) ? (a.n - blk_start) : (uint64_t)kBlock;
     // convert.c:104-110 then demod_2400.c:484-485
-    const double mean_level = (double)a.block_sums[2 * blk] / 65536.0 / (double)(unsigned)blk_len;
-    const double mean_power = (double)a.block_sums[2 * blk + 1] / 65535.0 / 65535.0 / (double)(unsigned)blk_len;
+    const double mean_level = a.block_means ? a.block_means[2 * blk] : (double)a.block_sums[2 * blk] / 65536.0 / (double)(unsigned)blk_len;
+    const double mean_power = a.block_means ? a.block_means[2 * blk + 1] : (double)a.block_sums[2 * blk + 1] / 65535.0 / 65535.0 / (double)(unsigned)blk_len;
     const double noise_stddev = sqrt(mean_power - mean_level * mean_level);
     const unsigned noise_level = (unsigned)((mean_power + noise_stddev) * 65535 + 0.5);
 
@@ -1377,11 +1417,19 @@ hipError_t launch_filter_rebuild(uint32_t *t0, uint32_t *t1, const uint32_t *add
     return hipGetLastError();
 }
 
+hipError_t launch_block_means_float(int fmt, const void *iq, uint64_t n, uint64_t blk_len, double *means, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    return by_format(fmt, [&](auto F) {
+        hipLaunchKernelGGL(k_block_means_float<decltype(F)::value>, dim3((unsigned)((n + blk_len - 1) / blk_len)), dim3(64), 0, s, iq, n, blk_len, means);
+        return hipGetLastError();
+    });
+}
+
 hipError_t launch_modeac(const BatchArgs &a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     return by_format(a.fmt, [&](auto F) {
         constexpr int fmt = decltype(F)::value;
-        hipLaunchKernelGGL(k_block_sums<fmt>, dim3(tiles_of(a.n)), dim3(kThreads), 0, s, a);
+        if (!a.block_means) hipLaunchKernelGGL(k_block_sums<fmt>, dim3(tiles_of(a.n)), dim3(kThreads), 0, s, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_modeac<fmt>, dim3(tiles_of(a.n)), dim3(kThreads), 0, s, a);

@@ -66,6 +66,7 @@ struct BatchArgs {
     uint32_t *adder_bitmap;  // 2^24 bits: superset of every address the filter can hold
     uint32_t *counters;
     uint64_t *block_sums;    // per 131072-block: sum(mag), sum(mag^2) over its new samples
+    const double *block_means; // or, when the caller already has them (struct mag_buf): mean_level, mean_power per block
     int emit_dead;           // also emit a marker item per gated offset (exact demod statistics)
     int keep_all;            // prune keeps every item (filter owned by the caller)
     int debug_flags;         // ablation only (RSB_ABL): 1 skip classify, 2 skip slicing loads, 4 skip reductions
@@ -109,6 +110,8 @@ hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *t
 // first-add tables := "never" everywhere, 0 for address 0 and the n given addresses
 hipError_t launch_filter_rebuild(uint32_t *t0, uint32_t *t1, const uint32_t *addrs_dev, uint32_t n, hipStream_t s);
 hipError_t launch_modeac(const BatchArgs &a, hipStream_t s);
+// SC16 / SC16Q11: per block of blk_len samples the reference's float32 running sums, as means (level, power)
+hipError_t launch_block_means_float(int fmt, const void *iq, uint64_t n, uint64_t blk_len, double *means, hipStream_t s);
 hipError_t launch_convert(int fmt, const void *iq, uint16_t *mag, uint64_t n, const uint16_t *lut, uint64_t *sums, hipStream_t s);
 
 }  // namespace rsb

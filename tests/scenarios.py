@@ -35,7 +35,7 @@ SCENARIOS.update({
 })
 
 # scenarios the GPU path supports today
-GPU_SCENARIOS = [k for k, (sc, kw) in SCENARIOS.items() if not kw.get("dc_filter") and not (kw["modeac"] and sc.fmt != "UC8")]
+GPU_SCENARIOS = [k for k, (sc, kw) in SCENARIOS.items() if not kw.get("dc_filter")]
 
 # converter known-answer cases: name -> (format, dc_filter, samples, samples per converter call)
 CONVERT_CASES = {

@@ -1,0 +1,115 @@
+"""include/readsb_dropin.h: the reference-signature entry points.  CRC calls on the CPU; converter and the two
+per-block demodulators on the GPU, driven block by block the way sdr_ifile.c:184-228 drives the reference."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import readsb_amd
+from readsb_amd import dropin
+from oracle.oracle import Oracle, REC_DTYPE, first_mismatch
+from readsb_amd.synth import generate
+
+from scenarios import CONVERT_CASES, SCENARIOS, convert_input
+from test_oracle import GOLD
+
+B, T = readsb_amd.BLOCK, readsb_amd.TRAILING
+
+
+def test_symbols_bound():
+    l = dropin.dlib()
+    for name in dropin.SYMBOLS:
+        assert hasattr(l, name)
+
+
+@pytest.mark.parametrize("nfix", [1, 2])
+def test_crc_calls_match_reference_tables(nfix):
+    l = dropin.dlib()
+    z = np.load(os.path.join(GOLD, f"crctab_fix{nfix}.npz"))
+    l.rsbd_modesChecksumInit(nfix)
+    for bits, key in ((56, "short"), (112, "long")):
+        rows = z[key]
+        for syn, errors, b0, b1 in rows[:: max(1, len(rows) // 97)]:
+            ei = l.rsbd_modesChecksumDiagnose(int(syn), bits)
+            assert ei and (ei.contents.syndrome, ei.contents.errors) == (syn, errors)
+            assert ei.contents.bit[0] == b0 and (errors < 2 or ei.contents.bit[1] == b1)
+            # a frame with exactly those bits flipped has that syndrome, and Fix restores it (crc.c:410-418)
+            msg = bytearray((i * 29 + 5) & 255 for i in range(bits // 8))
+            buf = (C.c_uint8 * 14).from_buffer_copy(bytes(msg) + bytes(14 - len(msg)))
+            crc = l.rsbd_modesChecksum(buf, bits)
+            n = bits // 8
+            buf[n - 3] ^= (crc >> 16) & 255
+            buf[n - 2] ^= (crc >> 8) & 255
+            buf[n - 1] ^= crc & 255
+            assert l.rsbd_modesChecksum(buf, bits) == 0
+            clean = bytes(buf)
+            for b in (b0, b1)[:errors]:
+                buf[b >> 3] ^= 1 << (7 - (b & 7))
+            assert l.rsbd_modesChecksum(buf, bits) == syn
+            l.rsbd_modesChecksumFix(buf, ei)
+            assert bytes(buf) == clean
+    none = l.rsbd_modesChecksumDiagnose(0, 112)
+    assert none and none.contents.errors == 0  # NO_ERRORS, crc.c:389-390
+    assert not l.rsbd_modesChecksumDiagnose(0x123457, 56) or nfix  # uncorrectable syndromes give NULL
+    l.rsbd_crcCleanupTables()
+    assert not l.rsbd_modesChecksumDiagnose(int(z["long"][0][0]), 112)
+
+
+def test_init_converter_rejects_like_the_reference(capfd):
+    l = dropin.dlib()
+    st = C.c_void_p()
+    assert not l.rsbd_init_converter(7, 2.4e6, 0, C.byref(st)) and not st.value
+    assert "no suitable converter for format=7 dc=0" in capfd.readouterr().err  # convert.c:460-464
+    assert not l.rsbd_init_converter(0, 2.4e6, 1, C.byref(st))  # --dcfilter: not on the GPU path yet
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [k for k, v in CONVERT_CASES.items() if not v[1]])
+def test_converter_matches_oracle(case, built):
+    fmt, dc, n, chunk = CONVERT_CASES[case]
+    iq = convert_input(fmt, n)
+    conv = dropin.Converter(readsb_amd.FORMATS[fmt])
+    orc = Oracle(fmt=fmt)
+    for lo in range(0, n, chunk):
+        part = iq[lo:lo + chunk]
+        mag, lvl, pwr = conv(part)
+        wmag, wlvl, wpwr = orc.convert(part)
+        assert np.array_equal(mag, wmag)
+        assert (lvl, pwr) == (wlvl, wpwr)  # SC16: float32 running sums taken in sample order on the device
+    conv.close()
+
+
+def feed_blocks(modes, orc, iq, modeac):
+    """sdr_ifile.c:184-228: 131072-sample reads, 326 samples of overlap from the previous buffer, and the
+    final short (possibly empty) block at EOF."""
+    iq = iq.reshape(-1, 2)
+    n = iq.shape[0]
+    prev_tail = np.zeros(T, dtype=np.uint16)
+    pos = 0
+    while True:
+        part = iq[pos:pos + B]
+        length = part.shape[0]
+        if length:
+            mag, lvl, pwr = orc.convert(part)
+        else:
+            mag, lvl, pwr = np.zeros(0, dtype=np.uint16), 0.0, 0.0
+        data = np.concatenate([prev_tail, mag, np.zeros(T, dtype=np.uint16)])  # the buffer is allocated with the overlap room
+        modes.block(data, length, pos * 5, lvl, pwr, modeac)
+        if length < B:
+            break
+        prev_tail = data[length:length + T].copy()  # lastbuf->data + lastbuf->length
+        pos += B
+    return modes.messages()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mixed_fix1", "dense_fix2_ac", "exact_2_blocks", "short_5000", "sc16_ac"])
+def test_block_demodulators_match_oracle(name, built):
+    sc, kw = SCENARIOS[name]
+    iq = generate(sc)
+    want, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
+    modes = dropin.Modes(nfix_crc=kw["nfix"])
+    got = feed_blocks(modes, Oracle(fmt=sc.fmt), iq, kw["modeac"])
+    assert first_mismatch(want, got.view(REC_DTYPE)) is None
+    modes.close()
