@@ -81,6 +81,7 @@ def main() -> int:
     import torch.distributed as dist
 
     import readsb_amd
+    from readsb_amd import dist as rd
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,7 +97,7 @@ def main() -> int:
     seg_n = min(args.segment, n)
     reps = n // seg_n
     n = reps * seg_n
-    seg = make_segment(seg_n, seed=1000 + rank)  # every rank = its own receiver channel
+    seg = make_segment(seg_n, seed=rd.channel_seed(rank))  # every rank = its own receiver channel
     seg_dev = torch.from_numpy(seg).to(dev)
     iq = seg_dev.repeat(reps, 1).contiguous()  # (n, 2) uint8 = the resident recording
     del seg_dev
@@ -114,9 +115,7 @@ def main() -> int:
         return ch.collect(out=outbuf)
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        rd.barrier(dev)
 
     for _ in range(args.warmup):
         msgs = step()
@@ -132,14 +131,8 @@ def main() -> int:
             tm[k].append(t[k])
     barrier()
     dt = time.perf_counter() - t0
-    nmsgs = int(msgs.size)
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(counts, torch.tensor([nmsgs], dtype=torch.int64, device=dev))  # the result-count gather
-        nmsgs = int(sum(int(c.item()) for c in counts))
+    dt = rd.max_over_ranks(dt, dev)                      # the slowest rank's time
+    nmsgs = sum(rd.gather_counts(int(msgs.size), dev))   # the result-count gather: the only data the ranks exchange
 
     # full-size check: the recording is `reps` copies of one segment whose length is a multiple of
     # 131072, so from the second copy on (filter warm, real overlap) every copy must decode to the same
@@ -155,6 +148,13 @@ def main() -> int:
         parity = "periodic-ok" if same else "PERIODICITY-MISMATCH"
 
     if rank == 0:
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/hbm_traffic.py from rocprofv3 --pmc passes
+        if os.path.exists(tfile):
+            with open(tfile) as f:
+                t = json.load(f)
+            if t.get("samples") == n:
+                traffic = t.get("bytes_per_launch")
         scan_s = float(np.mean(scan_ms)) / 1e3
         achieved = 2.0 * n / scan_s / 1e9
         st = ch.stats()
@@ -176,7 +176,7 @@ def main() -> int:
                        "channels": world, "messages_per_step": nmsgs, "survivors_per_step": st["survivors"],
                        "full_size_check": parity},
             "roofline": {"bound": "hbm", "kernel": "k_scan<UC8>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": 2 * n, "avg_launch_ms": scan_s * 1e3},
             "stage_ms": {"scan": float(np.mean(tm["scan_ms"])), "prune": float(np.mean(tm["prune_ms"])), "sort": float(np.mean(tm["sort_ms"])),
                          "device_replay": float(np.mean(tm["device_replay_ms"])), "copy_out": float(np.mean(tm["copy_ms"])),
