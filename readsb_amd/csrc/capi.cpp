@@ -80,7 +80,7 @@ int setup_device(rsb_ctx *c) {
     if (const char *e = std::getenv("RSB_ABL")) c->debug_flags = std::atoi(e);
     if (const char *e = std::getenv("RSB_SCAN_GRID")) c->scan_grid = std::atoi(e);
     HIP_TRY(c, hipMalloc((void **)&c->d_items, (size_t)c->item_cap * sizeof(ItemRec)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_region_counts, (size_t)c->scan_grid * 16 * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_region_counts, (size_t)c->scan_grid * kScanWavesPerGroup * sizeof(uint32_t)));
     for (int w = 0; w < 2; ++w) {
         HIP_TRY(c, hipMalloc((void **)&c->d_skeys[w], (size_t)c->surv_item_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_sinfo[w], (size_t)c->surv_item_cap * sizeof(uint32_t)));

@@ -107,9 +107,9 @@ struct rsb_ctx {
         a.items = d_items;
         {
             // one item region per wavefront that will actually run (launch_scan shrinks the grid for small batches)
-            const uint64_t nstrips = (n + 2 + 2047) / 2048, need = (nstrips + 15) / 16;
+            const uint64_t nstrips = (n + 2 + rsb::kScanStrip - 1) / rsb::kScanStrip, need = (nstrips + rsb::kScanWavesPerGroup - 1) / rsb::kScanWavesPerGroup;
             const uint32_t grid = (uint32_t)(need < (uint64_t)scan_grid ? (need ? need : 1) : (uint64_t)scan_grid);
-            a.n_regions = grid * 16u;
+            a.n_regions = grid * (uint32_t)rsb::kScanWavesPerGroup;
         }
         a.shared_cap = item_cap / 16;
         a.item_region = (item_cap - a.shared_cap) / a.n_regions;

@@ -349,37 +349,61 @@ __device__ void slow_item(const BatchArgs &a, const uint16_t *d, uint32_t g, int
 // ------------------------------------------------------------------------------------------------
 // the scan kernel: wave-autonomous strips
 //
-// One 1024-thread workgroup per CU shares the 32 KB folded UC8 table; after that each of its 16
-// wavefronts works alone on strips of 2048 scan offsets with its own 7.6 KB of LDS (magnitudes of
-// the strip + 304-sample halo, and three small queues).  A strip goes through all stages inside
-// its wavefront, so no workgroup barrier is ever executed: while one wavefront is in a stage that
-// keeps few lanes busy, the other wavefronts of the SIMD are in other stages.
+// One 768-thread workgroup per CU shares the 32 KB folded UC8 table and the small CRC tables; after
+// that each of its 12 wavefronts works alone on strips of 3792 scan offsets with its own 9.75 KB of
+// LDS (4096 magnitudes = the strip + a 304-sample halo, and three small queues).  A strip goes
+// through all stages inside its wavefront, so no workgroup barrier is ever executed: while one
+// wavefront is in a stage that keeps few lanes busy, the other wavefronts of the SIMD are in others.
+//
+//   1. convert: 8 passes, lane l of pass t owns the 8 samples of chunk 64t + l (one 16-byte load of
+//      raw IQ per pass, fetched one strip ahead into registers).  While the chunk is still in registers
+//      the comparisons m[s] < m[s+1] and m[s] > m[s+1] are taken with packed saturating subtracts and
+//      their sign bits shifted into bit-sliced words: byte k of a lane's word, bit t = sample k of
+//      chunk 64t + l.
+//   2. the edge patterns of demod_2400.c:109-155 on those words: "sample s + j" is byte (k + j) % 8
+//      of this lane, the next lane or the one after, so a shift is a v_alignbyte and every logic
+//      instruction decides 4 offsets x 8 passes per lane, 2048 offsets per wavefront.
+//   3. the ~5 % of offsets that survive are compacted into an LDS queue and take the arithmetic gate
+//      (:158-172), one lane per offset.
+//   4. (gated offset, trial phase) pairs, one lane each: the first five bits (the DF) decide the
+//      length class (:272-285).
+//   5. one lane per frame: all 56 / 112 bits, CRC syndrome by linearity, classification -> item.
+//
+// Slicing: bit k = 5u + v of trial phase tp is the sign of correlator (tp + 12v) % 5 at sample
+// e0 + 12u + (tp + 12v) / 5.  Whatever tp (4..8) and the parity of e0, the taps of bit v of a group
+// fall into three consecutive dwords of LDS at a fixed position relative to dword (e0 >> 1) + 6u:
+// {0,1,2}, {1,2,3}, {2,3,4}, {4,5,6}, {5,6,7} for v = 0..4.  So every lane runs the same three
+// v_dot2_i32_i16 per bit on statically indexed registers, and phase + alignment only select the
+// lane's 15 packed coefficient pairs (a 10-row table in LDS).
 
 constexpr int kBloomWords = 512;
 __device__ __forceinline__ uint32_t bloom_bit(uint32_t syn) { return (syn * 0x85EBCA6Bu) >> 18; }  // 14 bits
 
-constexpr int kStrip = 2048;                      // scan offsets per strip
-constexpr int kStripVecs = (kStrip + kHalo) / 8;  // 16-byte vectors of 8 magnitudes per strip (294)
-constexpr int kScanWaves = 16;
+constexpr int kPasses = 8;                       // 16-byte chunks per lane and strip
+constexpr int kRegion = kPasses * 64 * 8;        // magnitudes in LDS per strip
+constexpr int kStrip = kScanStrip;               // scan offsets per strip
+static_assert(kStrip == kRegion - kHalo && kStrip % 8 == 0, "strip + halo fill the region; strips start on 16-byte IQ boundaries");
+constexpr int kScanWaves = kScanWavesPerGroup;
 constexpr int kScanThreads = 64 * kScanWaves;
-constexpr int kTileShift = 2;   // strips start at S index k*2048 - 2: then their first IQ sample, k*2048 - 328, is a multiple of 8
-constexpr int kEdgeCap = 704;   // edge-pattern candidates of half a strip (at most 2 of any 3 consecutive offsets can pass)
+constexpr int kTileShift = 2;   // strips start at S index k*kStrip - 2: then their first IQ sample, k*kStrip - 328, is a multiple of 8
+constexpr int kEdgeCap = 512;   // edge-pattern candidates per strip that go through the queue; more take the per-thread path
 constexpr int kGateCap = 192;   // gated offsets per strip that go through the dense stages; more take the per-thread path
-constexpr int kListCap = 256;   // short / long items per strip in the dense stages
+constexpr int kListCap = 192;   // frames per strip in the dense slicing stage
+constexpr int kGsynShort = 0, kGsynLong = 12 * 32;  // short first: a finished 56-bit lane keeps reading entry 0 of long groups (zero)
 
 struct __attribute__((aligned(16))) WaveShared {
-    uint16_t m[kStrip + kHalo];
+    uint16_t m[kRegion];
     uint16_t eq[kEdgeCap];
     uint16_t gq[kGateCap];
-    uint16_t lst[2][kListCap];
+    uint16_t fl[kListCap];
 };
 static_assert(sizeof(WaveShared) % 16 == 0, "per-wave LDS regions must keep 16-byte alignment");
 
 struct __attribute__((aligned(16))) ScanShared {
     uint16_t lut[16384];
+    uint32_t coef[10][16];           // [parity of e0 * 5 + trial phase - 4][3 v + dword]: negated tap pairs
     uint32_t bloom[2][kBloomWords];  // one bit per hashed syndrome of the 56- / 112-bit repair table: most lookups end here
-    uint32_t gsyn_long[23 * 32];   // per 5-bit group of a 112-bit frame: XOR of the single-bit syndromes of the set bits
-    uint32_t gsyn_short[12 * 32];  // same for 56-bit frames
+    uint32_t gsyn[(12 + 23) * 32];   // per 5-bit group of a 56- / 112-bit frame: XOR of the single-bit syndromes of the set bits
     WaveShared w[kScanWaves];
 };
 static_assert(sizeof(ScanShared) <= 160 * 1024, "LDS budget of one CU");
@@ -397,15 +421,16 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // set bits of
 }
 
 __device__ __forceinline__ uint32_t uc8_pair(uint32_t x, const uint16_t *lut) {
-    // two UC8 samples (I0 Q0 I1 Q1) -> two magnitudes. |v - 127.5| - 0.5 per byte, then the folded
-    // 128 x 128 table; the XOR spreads rows over LDS banks (small signals otherwise hit few banks)
-    const uint32_t t = (~x >> 7) & 0x01010101u;
-    const uint32_t f = (x ^ ((t << 7) - t)) & 0x7f7f7f7fu;
-    uint32_t i0 = (f & 0x7f) | ((f >> 1) & 0x3f80);
-    uint32_t i1 = ((f >> 16) & 0x7f) | ((f >> 17) & 0x3f80);
-    i0 ^= (i0 >> 6) & 0x3e;
-    i1 ^= (i1 >> 6) & 0x3e;
-    return (uint32_t)lut[i0] | ((uint32_t)lut[i1] << 16);
+    // two UC8 samples (I0 Q0 I1 Q1) -> two biased magnitudes.  |v - 127.5| - 0.5 per byte is v ^ 0x80 (v >= 128)
+    // or v ^ 0x7f; then the folded 128 x 128 table at byte address 2 fI + 256 fQ, with fQ's low bits XOR-ed
+    // into the bank bits (small signals otherwise hit few banks)
+    const uint32_t t = (x >> 7) & 0x01010101u;
+    const uint32_t f = x ^ (0x7f7f7f7fu + t);
+    const uint32_t sw = (f >> 6) & 0x007c007cu;
+    const uint32_t a0 = ((f & 0xffffu) + (f & 0xffu)) ^ (sw & 0xffffu);
+    const uint32_t a1 = ((f >> 16) + ((f >> 16) & 0xffu)) ^ (sw >> 16);
+    const uint8_t *b = (const uint8_t *)lut;
+    return (uint32_t) * (const uint16_t *)(b + a0) | ((uint32_t) * (const uint16_t *)(b + a1) << 16);
 }
 
 template <int FMT>
@@ -458,67 +483,101 @@ __device__ uint32_t classify_fields(uint32_t w0, uint32_t syn, bool nonzero, con
     }
 }
 
-// butterfly reductions inside 4 / 8 / 16 consecutive lanes with DPP moves (no LDS traffic)
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
-}
-template <int SEG, typename OP>
-__device__ __forceinline__ uint32_t seg_reduce(uint32_t v, OP op) {
-    v = op(v, dpp_mov<0xB1>(v));                 // quad_perm [1,0,3,2]
-    v = op(v, dpp_mov<0x4E>(v));                 // quad_perm [2,3,0,1]
-    if (SEG >= 8) v = op(v, dpp_mov<0x141>(v));  // row_half_mirror: lane i <-> 7-i of each 8
-    if (SEG == 16) v = op(v, dpp_mov<0x140>(v)); // row_mirror: lane i <-> 15-i of each 16
-    return v;
+// lane i <- lane (i + 1) % 64 (DPP wave rotate; no LDS traffic)
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
 }
 
-// Group-parallel slicing of one frame by SEG lanes (4 for 56-bit frames, 8 for 112-bit frames): lane
-// `sub` of the segment slices the three 5-bit groups sub, sub + SEG and sub + 2 SEG (neighbouring lanes
-// then read LDS 24 bytes apart) and looks up the XOR of the syndromes of their set bits (the CRC is
-// linear: crc.c:59-64,140; one 32-entry table per group); the segment then reduces syndrome, first
-// message word and a non-zero flag.  Straight-line code: the one out-of-range group (23 of a long
-// frame) is clamped and masked instead of branched around.
-__device__ __forceinline__ uint32_t first_word_part(int G, uint32_t b) {  // where group G lands in message bits 0..31
-    return G < 6 ? (b << (27 - 5 * G)) : (G == 6 ? (b >> 3) : 0u);
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t x, uint32_t y) {  // v_pk_sub_i16 clamp: the sign bits are x < y per half
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(short2v, x), __builtin_bit_cast(short2v, y)));
 }
-template <bool LONG>
-__device__ __forceinline__ void slice_segment(const BatchArgs &a, const ScanShared &sh, const uint16_t *m, int e, uint32_t g, uint32_t phase,
-                                              uint32_t sub, bool valid, ItemRec *region, uint32_t &nitems) {
-    constexpr int kSeg = LONG ? 8 : 4;
-    const uint32_t *gsyn = LONG ? sh.gsyn_long : sh.gsyn_short;
-    const RotSlicer rs(phase);
-    const int G0 = (int)sub, G1 = G0 + kSeg, G2 = G0 + 2 * kSeg;
-    const bool v2 = !LONG || G2 < 23;
-    const int H2 = v2 ? G2 : 0;
-    uint32_t b0 = 21, b1 = 10, b2 = 5;
-    if (!(a.debug_flags & 2)) {
-        b0 = rs.group(m, e, G0);
-        b1 = rs.group(m, e, G1);
-        b2 = rs.group(m, e, H2);
+
+// The comparisons of one chunk (8 biased samples in p, the next chunk's first pair in nx) shifted into
+// the bit-sliced words: after the 8 passes of a strip, bits 8..15 of accL[i] hold m[s] < m[s+1] for
+// sample 2i of the lane's chunks (bit 8 + t = pass t), bits 24..31 the same for sample 2i + 1; accG: '>'.
+__device__ __forceinline__ void edge_accumulate(const uint4 &p, uint32_t nx, uint32_t (&accL)[4], uint32_t (&accG)[4]) {
+    const uint32_t d[5] = {p.x, p.y, p.z, p.w, nx};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t n = __builtin_amdgcn_alignbit(d[i + 1], d[i], 16);  // samples 2i+1, 2i+2
+        accL[i] = (accL[i] >> 1) | (pk_sub_sat(d[i], n) & 0x80008000u);
+        accG[i] = (accG[i] >> 1) | (pk_sub_sat(n, d[i]) & 0x80008000u);
     }
-    if (!LONG) {  // group 11 holds bits 55..59: only bit 55 belongs to the frame
-        b2 = (G2 == 11) ? (b2 & 16u) : b2;
-    } else {      // group 22 holds bits 110..114: only 110 and 111 belong to the frame
-        b2 = (G2 == 22) ? (b2 & 24u) : b2;
-        b2 = v2 ? b2 : 0u;
+}
+
+// bytes [R3 R2 R1 R0] of a lane -> the same for the lane's next chunk: the next lane, except that the
+// chunk after 64t + 63 is chunk 64(t + 1) + 0: lane 0, one pass later
+__device__ __forceinline__ uint32_t next_chunk(uint32_t x, uint32_t lane) {
+    const uint32_t r = from_next_lane(x);
+    return lane == 63 ? ((r >> 1) & 0x7f7f7f7fu) : r;
+}
+
+// word X[r] holds samples 4r..4r+3 of (this lane's chunk ++ the next ++ the one after); the four
+// samples starting at sample j
+template <int J>
+__device__ __forceinline__ uint32_t quad_at(const uint32_t (&X)[5]) {
+    if constexpr (J % 4 == 0) return X[J / 4];
+    else return __builtin_amdgcn_alignbyte(X[J / 4 + 1], X[J / 4], J % 4);
+}
+
+// demod_2400.c:109-151 for the four offsets 4Q..4Q+3 of each of the lane's 8 chunks: the quick check
+// and the five peak patterns OR-ed together
+template <int Q>
+__device__ __forceinline__ uint32_t edge_patterns(const uint32_t (&L)[5], const uint32_t (&G)[5]) {
+    constexpr int o = 4 * Q;
+    const uint32_t l0 = quad_at<o + 0>(L), l2 = quad_at<o + 2>(L), l3 = quad_at<o + 3>(L), l8 = quad_at<o + 8>(L), l9 = quad_at<o + 9>(L),
+                   l10 = quad_at<o + 10>(L), l11 = quad_at<o + 11>(L);
+    const uint32_t g1 = quad_at<o + 1>(G), g2 = quad_at<o + 2>(G), g3 = quad_at<o + 3>(G), g4 = quad_at<o + 4>(G), g9 = quad_at<o + 9>(G),
+                   g10 = quad_at<o + 10>(G), g12 = quad_at<o + 12>(G);
+    const uint32_t A = g1 & l2, B = l3 & g4, C = l8 & g9, D = g10 & l11;
+    const uint32_t p12 = A & g3 & C & (l10 | l11);
+    const uint32_t p345 = ((A & g4 & l8) | (B & l9 & (g1 | g2))) & D;
+    return (p12 | p345) & l0 & g12;
+}
+
+constexpr int kGroupDword[5] = {0, 1, 2, 4, 5};  // first of the three dwords that hold the taps of bit v of a 5-bit group
+
+// one entry of the coefficient table: the NEGATED taps (so that "bit is 1" is the sign bit of the sum) of
+// bit v that fall into dword kGroupDword[v] + t, for a frame whose first data sample has parity `par`
+__device__ uint32_t coef_entry(int par, int phase, int v, int t) {
+    const int taps[5][4] = {{5, -3, -2, 0}, {4, -1, -3, 0}, {3, 1, -4, 0}, {2, 3, -5, 0}, {1, 5, -5, -1}};  // demod_2400.c:48-66
+    const int P = phase + 4 + 12 * v, base = par + P / 5, phi = P % 5;
+    int lo = 0, hi = 0;
+    for (int x = 0; x < 4; ++x) {
+        const int r = base + x;
+        if ((r >> 1) - kGroupDword[v] != t) continue;
+        if (r & 1) hi = -taps[phi][x]; else lo = -taps[phi][x];
     }
-    uint32_t syn = gsyn[G0 * 32 + b0] ^ gsyn[G1 * 32 + b1] ^ gsyn[H2 * 32 + b2];  // entry 0 of every group is 0
-    // groups 0..6 make up message bits 0..34; keep the first 32 (DF + AA)
-    uint32_t w0 = first_word_part(G0, b0) | (LONG ? 0u : first_word_part(G1, b1));
-    uint32_t nz = b0 | b1 | b2;
-    if (!(a.debug_flags & 4)) {
-        syn = seg_reduce<kSeg>(syn, [](uint32_t x, uint32_t y) { return x ^ y; });
-        w0 = seg_reduce<kSeg>(w0, [](uint32_t x, uint32_t y) { return x | y; });
-        if (!LONG) nz = seg_reduce<kSeg>(nz, [](uint32_t x, uint32_t y) { return x | y; });  // only 56-bit frames are checked (mode_s.c:325)
+    return pk16(lo, hi);
+}
+
+// the five bits of one group: D = the 8 dwords at (e0 >> 1) + 6u, c = the lane's 15 coefficient pairs
+__device__ __forceinline__ uint32_t slice_group(const uint32_t (&D)[8], const uint32_t (&c)[15]) {
+    uint32_t b = 0;
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+        const int d = kGroupDword[v];
+        const int r = sdot2(D[d], c[3 * v], sdot2(D[d + 1], c[3 * v + 1], sdot2(D[d + 2], c[3 * v + 2], 0)));
+        b = __builtin_amdgcn_alignbit(b, (uint32_t)r, 31);  // b << 1 | sign
     }
-    uint32_t cls = kDeadItem;
-    if (valid && sub == 0 && !(a.debug_flags & 1)) cls = classify_fields<LONG>(w0, syn, nz != 0, a.tab, a.adder_bitmap, sh.bloom[LONG ? 1 : 0]);
-    const uint64_t em = __ballot(cls != kDeadItem);
-    if (cls != kDeadItem) {
-        const uint32_t pos = nitems + lanes_below(em);
-        if (pos < a.item_region) region[pos] = ItemRec{g, cls | (phase << 24)};
-    }
-    nitems += __popcll(em);
+    return b;
+}
+
+__device__ __forceinline__ void load_coefs(const ScanShared &sh, uint32_t e0, uint32_t phase, uint32_t (&c)[15]) {
+    const uint4 *row = (const uint4 *)sh.coef[(e0 & 1u) * 5u + phase];
+    const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+    c[0] = r0.x; c[1] = r0.y; c[2] = r0.z; c[3] = r0.w; c[4] = r1.x; c[5] = r1.y; c[6] = r1.z; c[7] = r1.w;
+    c[8] = r2.x; c[9] = r2.y; c[10] = r2.z; c[11] = r2.w; c[12] = r3.x; c[13] = r3.y; c[14] = r3.z;
+}
+
+// the whole gate on one offset, then every phase on the per-thread path (queue overflow only)
+__device__ void slow_offset(const BatchArgs &a, const uint16_t *m, uint32_t j, int64_t s0) {
+    const int64_t g = s0 + j;
+    if (g < 0 || (uint64_t)g >= a.n || !preamble_gate(m, (int)j)) return;
+    atomicAdd(&a.counters[kCntGated], 1u);
+    atomicAdd(&a.counters[kCntSlowPath], 1u);
+    if (a.emit_dead) emit_item_shared(a, (uint32_t)g, (kComboMarker << 27) | (7u << 24));
+    for (int p = 0; p < 5; ++p) slow_item(a, &m[j + 19], (uint32_t)g, p, a.tab.crc_bytes);
 }
 
 template <int FMT>
@@ -533,16 +592,20 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             sh.lut[i ^ ((aq & 31) << 1)] = (uint16_t)(a.tab.uc8_lut[((128 + aq) << 8) | (128 + ai)] ^ kBias);
         }
     for (uint32_t i = tid; i < 2 * kBloomWords; i += kScanThreads) sh.bloom[0][i] = 0;
-    for (uint32_t i = tid; i < 23 * 32 + 12 * 32; i += kScanThreads) {
+    for (uint32_t i = tid; i < 160; i += kScanThreads) {
+        const uint32_t row = i >> 4, e = i & 15;
+        sh.coef[row][e] = e < 15 ? coef_entry((int)(row / 5), (int)(row % 5), (int)(e / 3), (int)(e % 3)) : 0u;
+    }
+    for (uint32_t i = tid; i < (12 + 23) * 32; i += kScanThreads) {
         // crc.c:59-64: bit k of an n-bit frame has the syndrome of bit k + 112 - n of a 112-bit frame
-        const bool lng = i < 23 * 32;
-        const uint32_t e = lng ? i : i - 23 * 32, G = e >> 5, v = e & 31, nbits = lng ? 112 : 56;
+        const bool lng = i >= (uint32_t)kGsynLong;
+        const uint32_t e = lng ? i - kGsynLong : i, G = e >> 5, v = e & 31, nbits = lng ? 112 : 56;
         uint32_t x = 0;
         for (uint32_t j = 0; j < 5; ++j) {
             const uint32_t k = 5 * G + j;
             if (((v >> (4 - j)) & 1) && k < nbits) x ^= a.tab.sbs[k + 112 - nbits];
         }
-        (lng ? sh.gsyn_long : sh.gsyn_short)[e] = x;
+        sh.gsyn[i] = x;
     }
     __syncthreads();
     for (int which = 0; which < 2; ++which) {
@@ -560,20 +623,19 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     ItemRec *region = a.items + (size_t)gwave * a.item_region;
     uint32_t nitems = 0, gated_total = 0, slow_total = 0;  // wave-uniform
     const uint64_t nstrips = (a.n + kTileShift + kStrip - 1) / kStrip;
-    // The raw IQ of a strip is fetched one strip ahead into registers (5 x 16 bytes per lane), so the HBM
-    // latency of strip k + 1 hides behind the gate / slicing stages of strip k.
-    constexpr int kVecTrips = (kStripVecs + 63) / 64;
+    // The raw IQ of a strip is fetched one strip ahead into registers (8 x 16 bytes per lane and raw vector), so
+    // the HBM latency of strip k + 1 hides behind the gate / slicing stages of strip k.
     constexpr bool kVecFmt = (FMT == kFmtUC8 || FMT == kFmtSC16 || FMT == kFmtSC16Q11);
     constexpr int kRawVecs = (FMT == kFmtUC8) ? 1 : 2;  // 16-byte loads per 8 samples
-    uint4 pre[kVecTrips][kRawVecs];
-    auto vec_direct = [&](int64_t s0, int v) {  // can vector v of the strip at S index s0 be read as aligned raw IQ?
+    uint4 pre[kPasses][kRawVecs];
+    auto vec_direct = [&](int64_t s0, int v) {  // can chunk v of the strip at S index s0 be read as aligned raw IQ?
         const int64_t q = s0 + 8 * v - (int64_t)kTrailing;
-        return kVecFmt && a.iq_aligned && v < kStripVecs && q >= 0 && q + 8 <= (int64_t)a.n;
+        return kVecFmt && a.iq_aligned && q >= 0 && q + 8 <= (int64_t)a.n;
     };
     auto prefetch = [&](uint64_t strip) {
         const int64_t s0 = (int64_t)(strip * kStrip) - kTileShift;
 #pragma unroll
-        for (int t = 0; t < kVecTrips; ++t) {
+        for (int t = 0; t < kPasses; ++t) {
             const int v = (int)lane + 64 * t;
             if (strip < nstrips && vec_direct(s0, v)) {
                 const int64_t q = s0 + 8 * v - (int64_t)kTrailing;
@@ -589,11 +651,12 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         const int64_t s0 = (int64_t)(strip * kStrip) - kTileShift;  // S index of m[0]
         wave_sync();
 
-        // ---- convert.c: strip + halo -> magnitudes in LDS
+        // ---- convert.c: strip + halo -> magnitudes in LDS; comparisons of neighbours -> bit-sliced words
+        uint32_t accL[4] = {0, 0, 0, 0}, accG[4] = {0, 0, 0, 0};
+        uint4 prev = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < kVecTrips; ++t) {
+        for (int t = 0; t < kPasses; ++t) {
             const int v = (int)lane + 64 * t;
-            if (v >= kStripVecs) continue;
             uint4 o;
             if (vec_direct(s0, v)) {
                 if constexpr (FMT == kFmtUC8) {
@@ -611,90 +674,93 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 o = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
             }
             ((uint4 *)W.m)[v] = o;
+            // the chunk after this lane's chunk of pass t - 1 is the next lane's, or (lane 63) lane 0's of this pass
+            if (t > 0) edge_accumulate(prev, from_next_lane(lane == 0 ? o.x : prev.x), accL, accG);
+            prev = o;
         }
+        edge_accumulate(prev, from_next_lane(lane == 0 ? 0u : prev.x), accL, accG);  // chunk 511 has no successor: not a scan offset
         prefetch(strip + strip_step);
         wave_sync();
         if (a.stage_limit < 2) continue;
 
-        uint32_t ngated = 0;  // wave-uniform
-        for (int h = 0; h < 2; ++h) {
-            // ---- demod_2400.c:109-155, edge patterns only, 64 lanes x 8 consecutive offsets per ballot
-            uint32_t neq = 0;
-            for (int r = 0; r < 2; ++r) {
-                const int base = (h * 2 + r) * 512 + (int)lane * 8;
-                int w[22];  // biased samples: signed comparisons
-                const uint4 *src = (const uint4 *)&W.m[base];
+        // ---- demod_2400.c:109-155, edge patterns only, bit-parallel: 4 offsets x 8 passes per lane and instruction
+        uint32_t neq = 0;  // wave-uniform
+        {
+            uint32_t L[5], G[5];
+            L[0] = __builtin_amdgcn_perm(accL[1], accL[0], 0x07050301u);  // samples 0..3 of the lane's chunks
+            L[1] = __builtin_amdgcn_perm(accL[3], accL[2], 0x07050301u);  // samples 4..7
+            G[0] = __builtin_amdgcn_perm(accG[1], accG[0], 0x07050301u);
+            G[1] = __builtin_amdgcn_perm(accG[3], accG[2], 0x07050301u);
+            L[2] = next_chunk(L[0], lane);
+            L[3] = next_chunk(L[1], lane);
+            L[4] = next_chunk(L[2], lane);
+            G[2] = next_chunk(G[0], lane);
+            G[3] = next_chunk(G[1], lane);
+            G[4] = next_chunk(G[2], lane);
+            // pass 7 holds chunks 448 + lane: scan offsets only below chunk kStrip / 8
+            const uint32_t live = lane < (uint32_t)(kStrip / 8 - 448) ? 0xffffffffu : 0x7f7f7f7fu;
+            uint32_t E[2] = {edge_patterns<0>(L, G) & live, edge_patterns<1>(L, G) & live};
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const uint4 v = src[q];
-                    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (q * 8 + e * 2 < 22) w[q * 8 + e * 2] = (int)(int16_t)(d[e] & 0xffffu);
-                        if (q * 8 + e * 2 + 1 < 22) w[q * 8 + e * 2 + 1] = (int)d[e] >> 16;
+            for (int q = 0; q < 2; ++q) {
+                uint32_t e = E[q];
+                for (;;) {
+                    const uint64_t bm = __ballot(e != 0);
+                    if (!bm) break;
+                    if (e) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(e);
+                        e &= e - 1;
+                        const uint32_t j = ((b & 7u) << 9) | (lane << 3) | (4u * q + (b >> 3));  // pass, lane, sample of the chunk
+                        const uint32_t pos = neq + lanes_below(bm);
+                        if (pos < (uint32_t)kEdgeCap)
+                            W.eq[pos] = (uint16_t)j;
+                        else
+                            slow_offset(a, W.m, j, s0);
                     }
-                }
-                uint64_t L[21], G[21];  // L[j]: S[base+j] < S[base+j+1] per lane, G[j]: >
-#pragma unroll
-                for (int j = 0; j < 21; ++j) {
-                    L[j] = __ballot(w[j] < w[j + 1]);
-                    G[j] = __ballot(w[j] > w[j + 1]);
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint64_t *l = &L[k], *g = &G[k];
-                    // the five peak patterns of :112-151 OR-ed together, gated by the quick check of :109
-                    const uint64_t A = g[1] & l[2], B = l[3] & g[4], C = l[8] & g[9], D = g[10] & l[11];
-                    const uint64_t p12 = A & g[3] & C & (l[10] | l[11]);
-                    const uint64_t p345 = ((A & g[4] & l[8]) | (B & l[9] & (g[1] | g[2]))) & D;
-                    const uint64_t E = (p12 | p345) & l[0] & g[12];
-                    if ((E >> lane) & 1) {
-                        const uint32_t pos = neq + lanes_below(E);
-                        if (pos < (uint32_t)kEdgeCap) W.eq[pos] = (uint16_t)(base + k);
-                    }
-                    neq += __popcll(E);
+                    neq += __popcll(bm);
                 }
             }
-            wave_sync();
-            if (a.stage_limit < 3) continue;
-
-            // ---- the whole gate (:109-172) on the edge candidates; survivors go to the gated queue
-            neq = min(neq, (uint32_t)kEdgeCap);
-            for (uint32_t cb = 0; cb < neq; cb += 64) {
-                const uint32_t c = cb + lane;
-                uint32_t j = 0;
-                bool pass = false;
-                if (c < neq) {
-                    j = W.eq[c];
-                    const int64_t g = s0 + j;
-                    pass = g >= 0 && (uint64_t)g < a.n && preamble_gate(W.m, (int)j);
-                }
-                const uint64_t pm = __ballot(pass);
-                if (pass) {
-                    const uint32_t g = (uint32_t)(s0 + j);
-                    const uint32_t pos = ngated + lanes_below(pm);
-                    if (a.emit_dead) {
-                        const uint32_t ipos = nitems + lanes_below(pm);
-                        if (ipos < a.item_region) region[ipos] = ItemRec{g, (kComboMarker << 27) | (7u << 24)};
-                    }
-                    if (pos < (uint32_t)kGateCap) {
-                        W.gq[pos] = (uint16_t)j;
-                    } else {
-                        for (int p = 0; p < 5; ++p) slow_item(a, &W.m[j + 19], g, p, a.tab.crc_bytes);
-                    }
-                }
-                if (a.emit_dead) nitems += __popcll(pm);
-                ngated += __popcll(pm);
-            }
-            wave_sync();
         }
+        wave_sync();
+        if (a.stage_limit < 3) continue;
+
+        // ---- the whole gate (:109-172) on the edge candidates; survivors go to the gated queue
+        uint32_t ngated = 0;  // wave-uniform
+        neq = min(neq, (uint32_t)kEdgeCap);
+        for (uint32_t cb = 0; cb < neq; cb += 64) {
+            const uint32_t c = cb + lane;
+            uint32_t j = 0;
+            bool pass = false;
+            if (c < neq) {
+                j = W.eq[c];
+                const int64_t g = s0 + j;
+                pass = g >= 0 && (uint64_t)g < a.n && preamble_gate(W.m, (int)j);
+            }
+            const uint64_t pm = __ballot(pass);
+            if (pass) {
+                const uint32_t g = (uint32_t)(s0 + j);
+                const uint32_t pos = ngated + lanes_below(pm);
+                if (a.emit_dead) {
+                    const uint32_t ipos = nitems + lanes_below(pm);
+                    if (ipos < a.item_region) region[ipos] = ItemRec{g, (kComboMarker << 27) | (7u << 24)};
+                }
+                if (pos < (uint32_t)kGateCap) {
+                    W.gq[pos] = (uint16_t)j;
+                } else {
+                    for (int p = 0; p < 5; ++p) slow_item(a, &W.m[j + 19], g, p, a.tab.crc_bytes);
+                }
+            }
+            if (a.emit_dead) nitems += __popcll(pm);
+            ngated += __popcll(pm);
+        }
+        wave_sync();
         gated_total += ngated;
         if (ngated > (uint32_t)kGateCap) slow_total += ngated - kGateCap;
         if (a.stage_limit < 4) continue;
         const uint32_t ngq = min(ngated, (uint32_t)kGateCap);
+        const uint32_t *m32 = (const uint32_t *)W.m;
 
         // ---- first five bits (the DF) of every (offset, trial phase): which length class? (:272-285)
-        uint32_t nlist[2] = {0, 0};
+        uint32_t nlist = 0;
         for (uint32_t ib = 0; ib < 5 * ngq; ib += 64) {
             const uint32_t i = ib + lane;
             uint32_t cls = 2, j = 0, phase = 0;
@@ -702,59 +768,85 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 const uint32_t cand = i / 5;
                 phase = i - 5 * cand;
                 j = W.gq[cand];
-                const RotSlicer rs(phase);
-                const uint32_t df = rs.group(W.m, (int)j + 19, 0);
+                const uint32_t e0 = j + 19;
+                uint32_t c[15], D[8];
+                load_coefs(sh, e0, phase, c);
+                const uint32_t *mw = m32 + (e0 >> 1);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) D[k] = mw[k];
+                const uint32_t df = slice_group(D, c);
                 cls = ((kShortDfMask >> df) & 1) ? 0u : (((kLongDfMask >> df) & 1) ? 1u : 2u);
             }
-#pragma unroll
-            for (uint32_t k = 0; k < 2; ++k) {
-                const uint64_t cm = __ballot(cls == k);
-                if (cls == k) {
-                    const uint32_t pos = nlist[k] + lanes_below(cm);
-                    if (pos < (uint32_t)kListCap) {
-                        W.lst[k][pos] = (uint16_t)i;
-                    } else {
-                        slow_item(a, &W.m[j + 19], (uint32_t)(s0 + j), (int)phase, a.tab.crc_bytes);
-                    }
+            const uint64_t cm = __ballot(cls < 2);
+            if (cls < 2) {
+                const uint32_t pos = nlist + lanes_below(cm);
+                if (pos < (uint32_t)kListCap) {
+                    W.fl[pos] = (uint16_t)(i | (cls << 15));
+                } else {
+                    slow_item(a, &W.m[j + 19], (uint32_t)(s0 + j), (int)phase, a.tab.crc_bytes);
                 }
-                nlist[k] += __popcll(cm);
             }
+            nlist += __popcll(cm);
         }
-        if (nlist[0] > (uint32_t)kListCap) slow_total += nlist[0] - kListCap;
-        if (nlist[1] > (uint32_t)kListCap) slow_total += nlist[1] - kListCap;
+        if (nlist > (uint32_t)kListCap) slow_total += nlist - kListCap;
         wave_sync();
         if (a.stage_limit < 5) continue;
 
-        // ---- 56-bit frames: four lanes per frame, sixteen frames per pass
-        {
-            const uint32_t ns = min(nlist[0], (uint32_t)kListCap);
-            for (uint32_t cb = 0; cb < ns; cb += 16) {
-                const uint32_t c = cb + (lane >> 2);
-                const bool valid = c < ns;
-                uint32_t j = 0, phase = 0;
-                if (valid) {
-                    const uint32_t i = W.lst[0][c], cand = i / 5;
-                    phase = i - 5 * cand;
-                    j = W.gq[cand];
-                }
-                slice_segment<false>(a, sh, W.m, (int)j + 19, (uint32_t)(s0 + j), phase, lane & 3, valid, region, nitems);
+        // ---- one lane per frame: 12 (56 bits) or 23 (112 bits) groups of five bits
+        const uint32_t nfl = min(nlist, (uint32_t)kListCap);
+        for (uint32_t cb = 0; cb < nfl; cb += 64) {
+            const uint32_t ci = cb + lane;
+            const bool valid = ci < nfl;
+            uint32_t j = 0, phase = 0;
+            bool lng = false;
+            if (valid) {
+                const uint32_t ent = W.fl[ci], i = ent & 0x7fffu, cand = i / 5;
+                lng = (ent >> 15) != 0;
+                phase = i - 5 * cand;
+                j = W.gq[cand];
             }
-        }
-        if (a.stage_limit < 6) continue;
-        // ---- 112-bit frames: eight lanes per frame, eight frames per pass
-        {
-            const uint32_t nl = min(nlist[1], (uint32_t)kListCap);
-            for (uint32_t cb = 0; cb < nl; cb += 8) {
-                const uint32_t c = cb + (lane >> 3);
-                const bool valid = c < nl;
-                uint32_t j = 0, phase = 0;
-                if (valid) {
-                    const uint32_t i = W.lst[1][c], cand = i / 5;
-                    phase = i - 5 * cand;
-                    j = W.gq[cand];
-                }
-                slice_segment<true>(a, sh, W.m, (int)j + 19, (uint32_t)(s0 + j), phase, lane & 7, valid, region, nitems);
+            const bool any_long = __ballot(lng) != 0;
+            const uint32_t e0 = j + 19;
+            uint32_t c[15], D[8];
+            load_coefs(sh, e0, phase, c);
+            const uint32_t *mw = m32 + (e0 >> 1);
+            const uint32_t *gs = sh.gsyn + (lng ? kGsynLong : kGsynShort);
+            D[0] = mw[0];
+            D[1] = mw[1];
+            uint32_t syn = 0, w0 = 0, nz = 0;
+            auto group = [&](int u) {  // u is a constant after unrolling
+#pragma unroll
+                for (int k = 2; k < 8; ++k) D[k] = mw[6 * u + k];
+                uint32_t b = slice_group(D, c);
+                if (u == 11) b = lng ? b : (b & 16u);  // group 11 of a 56-bit frame: only bit 55 belongs to it
+                if (u > 11) b = lng ? b : 0u;          // a finished 56-bit frame keeps reading entry 0 (zero)
+                if (u == 22) b &= 24u;                 // group 22 holds bits 110..114: 110 and 111 belong to the frame
+                syn ^= gs[u * 32 + b];                 // the CRC is linear: crc.c:59-64,140
+                if (u < 6) w0 |= b << (27 - 5 * u);    // groups 0..6 make up message bits 0..34; keep the first 32 (DF + AA)
+                if (u == 6) w0 |= b >> 3;
+                if (u < 12) nz |= b;                   // only 56-bit frames are checked for all-zero (mode_s.c:325)
+                D[0] = D[6];
+                D[1] = D[7];
+            };
+#pragma unroll
+            for (int u = 0; u < 12; ++u) group(u);
+            if (any_long) {  // wave-uniform
+#pragma unroll
+                for (int u = 12; u < 23; ++u) group(u);
             }
+            uint32_t cls = kDeadItem;
+            if (valid) {
+                if (lng)
+                    cls = classify_fields<true>(w0, syn, true, a.tab, a.adder_bitmap, sh.bloom[1]);
+                else
+                    cls = classify_fields<false>(w0, syn, nz != 0, a.tab, a.adder_bitmap, sh.bloom[0]);
+            }
+            const uint64_t em = __ballot(cls != kDeadItem);
+            if (cls != kDeadItem) {
+                const uint32_t pos = nitems + lanes_below(em);
+                if (pos < a.item_region) region[pos] = ItemRec{(uint32_t)(s0 + j), cls | (phase << 24)};
+            }
+            nitems += __popcll(em);
         }
     }
     if (lane == 0) {

@@ -12,6 +12,10 @@ namespace rsb {
 // sample source formats a kernel can read; the first three are input_format_t (convert.h:29-32)
 enum : int { kFmtUC8 = 0, kFmtSC16 = 1, kFmtSC16Q11 = 2, kFmtMag16 = 3 };
 
+// geometry of the scan kernel that the host needs for sizing the item regions: scan offsets per strip, and
+// wavefronts (= private item regions) per workgroup
+constexpr int kScanStrip = 3792, kScanWavesPerGroup = 12;
+
 // device counters (one uint32 each)
 enum : int {
     kCntItems = 0,     // item records appended by the scan kernel
