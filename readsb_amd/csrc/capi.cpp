@@ -91,7 +91,7 @@ int setup_device(rsb_ctx *c) {
     HIP_TRY(c, hipMalloc((void **)&c->d_surv, (size_t)c->surv_cap * sizeof(Survivor)));
     HIP_TRY(c, hipMalloc((void **)&c->d_ac, (size_t)c->ac_cap * sizeof(AcCand)));
     HIP_TRY(c, hipMalloc((void **)&c->d_bitmap, (1u << 24) / 8));
-    HIP_TRY(c, hipMalloc((void **)&c->d_counters, kCntCount * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_counters, kCntAlloc * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_block_sums, c->nblocks_cap * 2 * sizeof(uint64_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_block_means, c->nblocks_cap * 2 * sizeof(double)));
     HIP_TRY(c, hipMalloc(&c->d_carry, kTrailing * 4));
@@ -279,7 +279,7 @@ int rsb_filter_expire(rsb_ctx *c) {
 }
 
 static int enqueue_batch(rsb_ctx *c, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCntCount * sizeof(uint32_t), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCntAlloc * sizeof(uint32_t), s));
     HIP_TRY(c, hipMemsetAsync(c->d_region_counts, 0, (size_t)a.n_regions * sizeof(uint32_t), s));
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     if (c->run_modes) HIP_TRY(c, launch_scan(a, c->scan_grid, s));
@@ -336,6 +336,15 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     uint32_t cnt[kCntCount];
     HIP_TRY(c, hipMemcpyAsync(cnt, c->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+#ifdef RSB_STAGE_CLOCKS
+    {
+        uint32_t dbg[kCntAlloc];
+        HIP_TRY(c, hipMemcpy(dbg, c->d_counters, sizeof(dbg), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "stage clocks (ticks/16 summed over waves): convert %u edge %u gate %u df %u slice %u | strips %u gate batches %u df batches %u slice batches %u | edge cands %u frames %u long %u gated %u\n",
+                     dbg[kDbgClkConvert], dbg[kDbgClkEdge], dbg[kDbgClkGate], dbg[kDbgClkDf], dbg[kDbgClkSlice], dbg[kDbgStrips], dbg[kDbgGateBatches], dbg[kDbgDfBatches],
+                     dbg[kDbgSliceBatches], dbg[kDbgEdgeCands], dbg[kDbgFrames], dbg[kDbgLongFrames], dbg[kCntGated]);
+    }
+#endif
     if (cnt[kCntOverflow] || cnt[kCntSurvItems] > c->surv_item_cap || cnt[kCntAc] > c->ac_cap) {
         char buf[200];
         std::snprintf(buf, sizeof(buf), "device queue overflow: %u item regions, kept items %u/%u, modeac %u/%u (lower rsb_config.queue_div)",

@@ -20,6 +20,24 @@
 // in the reference's x86-64 build.
 #include "kernels.hpp"
 
+#ifndef RSB_SLICE_PREFETCH
+#define RSB_SLICE_PREFETCH 1
+#endif
+#ifdef RSB_STAGE_CLOCKS
+#define DBG_DECL uint32_t dbg_clk[5] = {0, 0, 0, 0, 0}, dbg_cnt[7] = {0, 0, 0, 0, 0, 0, 0}; uint64_t dbg_t = __builtin_readcyclecounter();
+#define DBG_STAGE(k) { const uint64_t t_ = __builtin_readcyclecounter(); dbg_clk[k] += (uint32_t)((t_ - dbg_t) >> 4); dbg_t = t_; }
+#define DBG_COUNT(k, n) dbg_cnt[k] += (n);
+#define DBG_FLUSH if (lane == 0) { for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&a.counters[kDbgClkConvert + k_], dbg_clk[k_]); for (int k_ = 0; k_ < 7; ++k_) atomicAdd(&a.counters[kDbgStrips + k_], dbg_cnt[k_]); }
+#else
+#define DBG_DECL
+#define DBG_STAGE(k)
+#define DBG_COUNT(k, n)
+#define DBG_FLUSH
+#endif
+#ifndef RSB_PREFETCH_EARLY
+#define RSB_PREFETCH_EARLY 1
+#endif
+
 #include <hipcub/hipcub.hpp>
 
 #include <type_traits>
@@ -379,16 +397,16 @@ __device__ void slow_item(const BatchArgs &a, const uint16_t *d, uint32_t g, int
 constexpr int kBloomWords = 512;
 __device__ __forceinline__ uint32_t bloom_bit(uint32_t syn) { return (syn * 0x85EBCA6Bu) >> 18; }  // 14 bits
 
-constexpr int kPasses = 8;                       // 16-byte chunks per lane and strip
+constexpr int kPasses = kScanPasses;             // 16-byte chunks per lane and strip
 constexpr int kRegion = kPasses * 64 * 8;        // magnitudes in LDS per strip
 constexpr int kStrip = kScanStrip;               // scan offsets per strip
 static_assert(kStrip == kRegion - kHalo && kStrip % 8 == 0, "strip + halo fill the region; strips start on 16-byte IQ boundaries");
 constexpr int kScanWaves = kScanWavesPerGroup;
 constexpr int kScanThreads = 64 * kScanWaves;
 constexpr int kTileShift = 2;   // strips start at S index k*kStrip - 2: then their first IQ sample, k*kStrip - 328, is a multiple of 8
-constexpr int kEdgeCap = 512;   // edge-pattern candidates per strip that go through the queue; more take the per-thread path
-constexpr int kGateCap = 192;   // gated offsets per strip that go through the dense stages; more take the per-thread path
-constexpr int kListCap = 192;   // frames per strip in the dense slicing stage
+constexpr int kEdgeCap = 64 * kPasses - 128;   // edge-pattern candidates per strip that go through the queue; more take the per-thread path
+constexpr int kGateCap = 128;   // gated offsets per strip that go through the dense stages; more take the per-thread path
+constexpr int kListCap = 128;   // frames per strip in the dense slicing stage
 constexpr int kGsynShort = 0, kGsynLong = 12 * 32;  // short first: a finished 56-bit lane keeps reading entry 0 of long groups (zero)
 
 struct __attribute__((aligned(16))) WaveShared {
@@ -406,6 +424,7 @@ struct __attribute__((aligned(16))) ScanShared {
     uint32_t gsyn[(12 + 23) * 32];   // per 5-bit group of a 56- / 112-bit frame: XOR of the single-bit syndromes of the set bits
     WaveShared w[kScanWaves];
 };
+static_assert(kPasses >= 2 && kPasses <= 8 && kStrip / 8 > 64 * (kPasses - 1), "bit-sliced bytes hold up to 8 passes; the last pass must hold scan offsets");
 static_assert(sizeof(ScanShared) <= 160 * 1024, "LDS budget of one CU");
 
 // compiler-level ordering of this wavefront's own LDS traffic (the hardware executes a wave's LDS
@@ -420,17 +439,27 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // set bits of
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
-__device__ __forceinline__ uint32_t uc8_pair(uint32_t x, const uint16_t *lut) {
-    // two UC8 samples (I0 Q0 I1 Q1) -> two biased magnitudes.  |v - 127.5| - 0.5 per byte is v ^ 0x80 (v >= 128)
-    // or v ^ 0x7f; then the folded 128 x 128 table at byte address 2 fI + 256 fQ, with fQ's low bits XOR-ed
-    // into the bank bits (small signals otherwise hit few banks)
+__device__ __forceinline__ void uc8_addr(uint32_t x, uint32_t &a0, uint32_t &a1) {
+    // two UC8 samples (I0 Q0 I1 Q1) -> the byte addresses of their entries in the folded 128 x 128 table.
+    // |v - 127.5| - 0.5 per byte is v ^ 0x80 (v >= 128) or v ^ 0x7f; the entry lies at 2 fI + 256 fQ, with fQ's
+    // low bits XOR-ed into the bank bits (small signals otherwise hit few banks)
     const uint32_t t = (x >> 7) & 0x01010101u;
     const uint32_t f = x ^ (0x7f7f7f7fu + t);
     const uint32_t sw = (f >> 6) & 0x007c007cu;
-    const uint32_t a0 = ((f & 0xffffu) + (f & 0xffu)) ^ (sw & 0xffffu);
-    const uint32_t a1 = ((f >> 16) + ((f >> 16) & 0xffu)) ^ (sw >> 16);
+    a0 = ((f & 0xffffu) + (f & 0xffu)) ^ (sw & 0xffffu);
+    a1 = ((f >> 16) + ((f >> 16) & 0xffu)) ^ (sw >> 16);
+}
+__device__ __forceinline__ uint4 uc8_chunk(const uint4 x, const uint16_t *lut) {  // 8 samples -> 8 biased magnitudes
+    uint32_t a[8];
+    uc8_addr(x.x, a[0], a[1]);
+    uc8_addr(x.y, a[2], a[3]);
+    uc8_addr(x.z, a[4], a[5]);
+    uc8_addr(x.w, a[6], a[7]);
     const uint8_t *b = (const uint8_t *)lut;
-    return (uint32_t) * (const uint16_t *)(b + a0) | ((uint32_t) * (const uint16_t *)(b + a1) << 16);
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = *(const uint16_t *)(b + a[k]);  // all eight lookups in flight together
+    return make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
 }
 
 template <int FMT>
@@ -552,15 +581,29 @@ __device__ uint32_t coef_entry(int par, int phase, int v, int t) {
 }
 
 // the five bits of one group: D = the 8 dwords at (e0 >> 1) + 6u, c = the lane's 15 coefficient pairs
+__device__ __forceinline__ int sdot2_first(uint32_t a, uint32_t b) {  // VOP3 form with a literal 0 accumulator
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ uint32_t slice_group(const uint32_t (&D)[8], const uint32_t (&c)[15]) {
     uint32_t b = 0;
 #pragma unroll
     for (int v = 0; v < 5; ++v) {
         const int d = kGroupDword[v];
-        const int r = sdot2(D[d], c[3 * v], sdot2(D[d + 1], c[3 * v + 1], sdot2(D[d + 2], c[3 * v + 2], 0)));
+        const int r = sdot2(D[d], c[3 * v], sdot2(D[d + 1], c[3 * v + 1], sdot2_first(D[d + 2], c[3 * v + 2])));
         b = __builtin_amdgcn_alignbit(b, (uint32_t)r, 31);  // b << 1 | sign
     }
     return b;
+}
+
+// LDS window of a frame: dword q of the window that starts at the dword holding sample e0.  The byte address
+// goes through an empty asm so that the compiler keeps it in one register and reaches the window with the
+// instruction's immediate offsets (it otherwise folds the region's base into a fresh v_add per access).
+__device__ __forceinline__ lds_dword *frame_window(const uint16_t *m, uint32_t e0) {
+    uint32_t A = (uint32_t)(uintptr_t)m + ((e0 >> 1) << 2);
+    asm volatile("" : "+v"(A));
+    return (lds_dword *)(uintptr_t)A;
 }
 
 __device__ __forceinline__ void load_coefs(const ScanShared &sh, uint32_t e0, uint32_t phase, uint32_t (&c)[15]) {
@@ -580,11 +623,24 @@ __device__ void slow_offset(const BatchArgs &a, const uint16_t *m, uint32_t j, i
     for (int p = 0; p < 5; ++p) slow_item(a, &m[j + 19], (uint32_t)g, p, a.tab.crc_bytes);
 }
 
+// magnitudes of a whole region the slow way (per sample, any alignment, zero outside the stream): the first strip
+// of a batch (carry), the last ones (end of the stream) and unaligned input
+template <int FMT>
+__device__ void fill_region_general(const BatchArgs &a, uint16_t *m, int64_t s0, uint32_t lane) {
+    for (int v = (int)lane; v < kRegion / 8; v += 64) {
+        const int64_t s = s0 + 8 * v;
+        uint32_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = stream_mag<FMT>(a, s + k) ^ kBias;
+        ((uint4 *)m)[v] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    }
+}
+
 template <int FMT>
 __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
     ScanShared &sh = *reinterpret_cast<ScanShared *>(scan_lds);
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform: SGPR
 
     if (FMT == kFmtUC8)
         for (uint32_t i = tid; i < 16384; i += kScanThreads) {
@@ -628,59 +684,62 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     constexpr bool kVecFmt = (FMT == kFmtUC8 || FMT == kFmtSC16 || FMT == kFmtSC16Q11);
     constexpr int kRawVecs = (FMT == kFmtUC8) ? 1 : 2;  // 16-byte loads per 8 samples
     uint4 pre[kPasses][kRawVecs];
-    auto vec_direct = [&](int64_t s0, int v) {  // can chunk v of the strip at S index s0 be read as aligned raw IQ?
-        const int64_t q = s0 + 8 * v - (int64_t)kTrailing;
-        return kVecFmt && a.iq_aligned && q >= 0 && q + 8 <= (int64_t)a.n;
+    auto interior = [&](uint64_t strip) {  // wave-uniform: every chunk of the strip is aligned raw IQ (all strips but the first and the last few)
+        const int64_t q = (int64_t)(strip * kStrip) - kTileShift - (int64_t)kTrailing;
+        return kVecFmt && a.iq_aligned && strip < nstrips && q >= 0 && q + kRegion <= (int64_t)a.n;
     };
     auto prefetch = [&](uint64_t strip) {
-        const int64_t s0 = (int64_t)(strip * kStrip) - kTileShift;
+        if (!interior(strip)) return;
+        const int64_t q = (int64_t)(strip * kStrip) - kTileShift - (int64_t)kTrailing;
+        const uint4 *src0 = (const uint4 *)((const uint8_t *)a.iq + (FMT == kFmtUC8 ? 2 : 4) * q) + kRawVecs * (int)lane;
 #pragma unroll
-        for (int t = 0; t < kPasses; ++t) {
-            const int v = (int)lane + 64 * t;
-            if (strip < nstrips && vec_direct(s0, v)) {
-                const int64_t q = s0 + 8 * v - (int64_t)kTrailing;
-                const uint4 *src = (const uint4 *)((const uint8_t *)a.iq + (FMT == kFmtUC8 ? 2 : 4) * q);
+        for (int t = 0; t < kPasses; ++t)
 #pragma unroll
-                for (int r = 0; r < kRawVecs; ++r) pre[t][r] = src[r];
-            }
+            for (int r = 0; r < kRawVecs; ++r) pre[t][r] = src0[kRawVecs * 64 * t + r];
+    };
+    auto direct_chunk = [&](int t) {
+        if constexpr (FMT == kFmtUC8) {
+            return uc8_chunk(pre[t][0], sh.lut);
+        } else if constexpr (kVecFmt) {
+            const uint4 x0 = pre[t][0], x1 = pre[t][kRawVecs - 1];
+            return make_uint4(sc16_pair<FMT>(x0, 0), sc16_pair<FMT>(x0, 1), sc16_pair<FMT>(x1, 0), sc16_pair<FMT>(x1, 1));
+        } else {
+            return make_uint4(0, 0, 0, 0);
         }
     };
     const uint64_t strip_step = (uint64_t)gridDim.x * kScanWaves;
-    prefetch((uint64_t)blockIdx.x * kScanWaves + wave);
+    if (RSB_PREFETCH_EARLY) prefetch((uint64_t)blockIdx.x * kScanWaves + wave);
+    DBG_DECL
     for (uint64_t strip = (uint64_t)blockIdx.x * kScanWaves + wave; strip < nstrips; strip += strip_step) {
         const int64_t s0 = (int64_t)(strip * kStrip) - kTileShift;  // S index of m[0]
+        if (!RSB_PREFETCH_EARLY) prefetch(strip);
         wave_sync();
 
         // ---- convert.c: strip + halo -> magnitudes in LDS; comparisons of neighbours -> bit-sliced words
         uint32_t accL[4] = {0, 0, 0, 0}, accG[4] = {0, 0, 0, 0};
         uint4 prev = make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < kPasses; ++t) {
-            const int v = (int)lane + 64 * t;
-            uint4 o;
-            if (vec_direct(s0, v)) {
-                if constexpr (FMT == kFmtUC8) {
-                    const uint4 x = pre[t][0];
-                    o = make_uint4(uc8_pair(x.x, sh.lut), uc8_pair(x.y, sh.lut), uc8_pair(x.z, sh.lut), uc8_pair(x.w, sh.lut));
-                } else if constexpr (kVecFmt) {
-                    const uint4 x0 = pre[t][0], x1 = pre[t][kRawVecs - 1];
-                    o = make_uint4(sc16_pair<FMT>(x0, 0), sc16_pair<FMT>(x0, 1), sc16_pair<FMT>(x1, 0), sc16_pair<FMT>(x1, 1));
-                }
-            } else {
-                const int64_t s = s0 + 8 * v;
-                uint32_t e[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) e[k] = stream_mag<FMT>(a, s + k) ^ kBias;
-                o = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-            }
-            ((uint4 *)W.m)[v] = o;
+        auto take_chunk = [&](int t, const uint4 o) {
             // the chunk after this lane's chunk of pass t - 1 is the next lane's, or (lane 63) lane 0's of this pass
             if (t > 0) edge_accumulate(prev, from_next_lane(lane == 0 ? o.x : prev.x), accL, accG);
             prev = o;
+        };
+        if (interior(strip)) {
+#pragma unroll
+            for (int t = 0; t < kPasses; ++t) {
+                const uint4 o = direct_chunk(t);
+                ((uint4 *)W.m)[(int)lane + 64 * t] = o;
+                take_chunk(t, o);
+            }
+        } else {
+            fill_region_general<FMT>(a, W.m, s0, lane);
+            wave_sync();
+#pragma unroll
+            for (int t = 0; t < kPasses; ++t) take_chunk(t, ((const uint4 *)W.m)[(int)lane + 64 * t]);
         }
         edge_accumulate(prev, from_next_lane(lane == 0 ? 0u : prev.x), accL, accG);  // chunk 511 has no successor: not a scan offset
-        prefetch(strip + strip_step);
+        if (RSB_PREFETCH_EARLY) prefetch(strip + strip_step);
         wave_sync();
+        DBG_STAGE(0) DBG_COUNT(0, 1)
         if (a.stage_limit < 2) continue;
 
         // ---- demod_2400.c:109-155, edge patterns only, bit-parallel: 4 offsets x 8 passes per lane and instruction
@@ -697,8 +756,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             G[2] = next_chunk(G[0], lane);
             G[3] = next_chunk(G[1], lane);
             G[4] = next_chunk(G[2], lane);
-            // pass 7 holds chunks 448 + lane: scan offsets only below chunk kStrip / 8
-            const uint32_t live = lane < (uint32_t)(kStrip / 8 - 448) ? 0xffffffffu : 0x7f7f7f7fu;
+            // bit 8 - kPasses + t of a byte = pass t.  The last pass holds chunks 64 (kPasses - 1) + lane: scan offsets only
+            // below chunk kStrip / 8; the bits below the first pass are shifted-in leftovers of next_chunk()
+            constexpr uint32_t kPassBits = ((0xffu << (8 - kPasses)) & 0xffu) * 0x01010101u;
+            const uint32_t live = lane < (uint32_t)(kStrip / 8 - 64 * (kPasses - 1)) ? kPassBits : (kPassBits & 0x7f7f7f7fu);
             uint32_t E[2] = {edge_patterns<0>(L, G) & live, edge_patterns<1>(L, G) & live};
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -709,7 +770,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                     if (e) {
                         const uint32_t b = (uint32_t)__builtin_ctz(e);
                         e &= e - 1;
-                        const uint32_t j = ((b & 7u) << 9) | (lane << 3) | (4u * q + (b >> 3));  // pass, lane, sample of the chunk
+                        const uint32_t j = (((b & 7u) - (8 - kPasses)) << 9) | (lane << 3) | (4u * q + (b >> 3));  // pass, lane, sample of the chunk
                         const uint32_t pos = neq + lanes_below(bm);
                         if (pos < (uint32_t)kEdgeCap)
                             W.eq[pos] = (uint16_t)j;
@@ -721,6 +782,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             }
         }
         wave_sync();
+        DBG_STAGE(1) DBG_COUNT(4, neq)
         if (a.stage_limit < 3) continue;
 
         // ---- the whole gate (:109-172) on the edge candidates; survivors go to the gated queue
@@ -754,10 +816,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         }
         wave_sync();
         gated_total += ngated;
+        DBG_STAGE(2) DBG_COUNT(1, (neq + 63) / 64)
         if (ngated > (uint32_t)kGateCap) slow_total += ngated - kGateCap;
         if (a.stage_limit < 4) continue;
         const uint32_t ngq = min(ngated, (uint32_t)kGateCap);
-        const uint32_t *m32 = (const uint32_t *)W.m;
 
         // ---- first five bits (the DF) of every (offset, trial phase): which length class? (:272-285)
         uint32_t nlist = 0;
@@ -771,7 +833,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 const uint32_t e0 = j + 19;
                 uint32_t c[15], D[8];
                 load_coefs(sh, e0, phase, c);
-                const uint32_t *mw = m32 + (e0 >> 1);
+                lds_dword *mw = frame_window(W.m, e0);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) D[k] = mw[k];
                 const uint32_t df = slice_group(D, c);
@@ -790,6 +852,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         }
         if (nlist > (uint32_t)kListCap) slow_total += nlist - kListCap;
         wave_sync();
+        DBG_STAGE(3) DBG_COUNT(2, (5 * ngq + 63) / 64)
         if (a.stage_limit < 5) continue;
 
         // ---- one lane per frame: 12 (56 bits) or 23 (112 bits) groups of five bits
@@ -806,34 +869,55 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 j = W.gq[cand];
             }
             const bool any_long = __ballot(lng) != 0;
+            DBG_COUNT(3, 1) DBG_COUNT(6, (uint32_t)__popcll(__ballot(lng)))
             const uint32_t e0 = j + 19;
-            uint32_t c[15], D[8];
+            uint32_t c[15], D[8], N[6];
             load_coefs(sh, e0, phase, c);
-            const uint32_t *mw = m32 + (e0 >> 1);
-            const uint32_t *gs = sh.gsyn + (lng ? kGsynLong : kGsynShort);
-            D[0] = mw[0];
-            D[1] = mw[1];
-            uint32_t syn = 0, w0 = 0, nz = 0;
-            auto group = [&](int u) {  // u is a constant after unrolling
+            uint32_t A = (uint32_t)(uintptr_t)W.m + ((e0 >> 1) << 2);  // LDS byte address of the window's first dword
+            uint32_t T = (uint32_t)(uintptr_t)sh.gsyn + 4u * (lng ? kGsynLong : kGsynShort);  // ... of this group's syndrome row
+            {
+                lds_dword *mw = (lds_dword *)(uintptr_t)A;
 #pragma unroll
-                for (int k = 2; k < 8; ++k) D[k] = mw[6 * u + k];
-                uint32_t b = slice_group(D, c);
-                if (u == 11) b = lng ? b : (b & 16u);  // group 11 of a 56-bit frame: only bit 55 belongs to it
-                if (u > 11) b = lng ? b : 0u;          // a finished 56-bit frame keeps reading entry 0 (zero)
-                if (u == 22) b &= 24u;                 // group 22 holds bits 110..114: 110 and 111 belong to the frame
-                syn ^= gs[u * 32 + b];                 // the CRC is linear: crc.c:59-64,140
-                if (u < 6) w0 |= b << (27 - 5 * u);    // groups 0..6 make up message bits 0..34; keep the first 32 (DF + AA)
-                if (u == 6) w0 |= b >> 3;
-                if (u < 12) nz |= b;                   // only 56-bit frames are checked for all-zero (mode_s.c:325)
+                for (int k = 0; k < 8; ++k) D[k] = mw[k];
+            }
+            // Runtime loops (not 23 unrolled groups: the register allocator then keeps the whole stage in ~60 VGPRs).
+            // Per group: the next group's six new dwords go in flight first, the group's syndrome (crc.c:59-64,140:
+            // the CRC is linear) is looked up now and folded in one group later, so no group waits for LDS.
+            uint32_t syn = 0, look = 0, hi = 0, lo = 0;  // hi:lo = the message bits so far (only the first 55 matter)
+            auto group = [&](bool more, uint32_t keep) {
+                asm volatile("" : "+v"(A), "+v"(T));  // one address register each, the rest in the instructions' offsets
+                lds_dword *mw = (lds_dword *)(uintptr_t)A;
+                if (more) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) N[k] = mw[8 + k];
+                }
+                const uint32_t b = slice_group(D, c) & keep;
+                syn ^= look;
+                look = *(lds_dword *)(uintptr_t)(T + 4u * b);
                 D[0] = D[6];
                 D[1] = D[7];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) D[2 + k] = N[k];
+                A += 24;
+                T += 128;
+                return b;
             };
-#pragma unroll
-            for (int u = 0; u < 12; ++u) group(u);
-            if (any_long) {  // wave-uniform
-#pragma unroll
-                for (int u = 12; u < 23; ++u) group(u);
+            for (int u = 0; u < 11; ++u) {  // bits 0..54
+                const uint32_t b = group(true, 31u);
+                hi = __builtin_amdgcn_alignbit(hi, lo, 27);
+                lo = (lo << 5) | b;
             }
+            const uint32_t w0 = __builtin_amdgcn_alignbit(hi, lo, 23);  // message bits 0..31: DF + AA
+            // group 11: a 56-bit frame ends with its first bit (bit 55)
+            const uint32_t b11 = group(any_long, lng ? 31u : 16u);
+            const uint32_t nz = hi | lo | b11;  // only 56-bit frames are checked for all-zero (mode_s.c:325)
+            uint32_t syn_short = syn ^ look;
+            if (any_long) {  // wave-uniform; lanes with 56-bit frames run along and are discarded below
+                for (int u = 12; u < 22; ++u) group(true, 31u);
+                group(false, 24u);  // group 22 holds bits 110..114: 110 and 111 belong to the frame
+                syn ^= look;
+            }
+            syn = lng ? syn : syn_short;
             uint32_t cls = kDeadItem;
             if (valid) {
                 if (lng)
@@ -848,7 +932,9 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             }
             nitems += __popcll(em);
         }
+        DBG_STAGE(4) DBG_COUNT(5, nfl)
     }
+    DBG_FLUSH
     if (lane == 0) {
         a.region_counts[gwave] = nitems;
         if (gated_total) atomicAdd(&a.counters[kCntGated], gated_total);

@@ -14,7 +14,15 @@ enum : int { kFmtUC8 = 0, kFmtSC16 = 1, kFmtSC16Q11 = 2, kFmtMag16 = 3 };
 
 // geometry of the scan kernel that the host needs for sizing the item regions: scan offsets per strip, and
 // wavefronts (= private item regions) per workgroup
-constexpr int kScanStrip = 3792, kScanWavesPerGroup = 12;
+#ifndef RSB_SCAN_WAVES
+#define RSB_SCAN_WAVES 16
+#endif
+#ifndef RSB_SCAN_PASSES
+#define RSB_SCAN_PASSES 6
+#endif
+constexpr int kScanPasses = RSB_SCAN_PASSES;                 // 512-sample passes per strip (LDS region = 512 * passes magnitudes)
+constexpr int kScanStrip = 512 * kScanPasses - 304;          // ... of which the last 304 are look-ahead only
+constexpr int kScanWavesPerGroup = RSB_SCAN_WAVES;
 
 // device counters (one uint32 each)
 enum : int {
@@ -32,7 +40,11 @@ enum : int {
     kCntAccE0,         // device replay: accepted messages by corrected bits (0, 1, 2)
     kCntAccE1,
     kCntAccE2,
-    kCntCount = 16
+    kCntCount = 16,
+    // RSB_STAGE_CLOCKS builds only: per-stage wave time of the scan kernel (s_memtime ticks >> 4) and work counts
+    kDbgClkConvert = 16, kDbgClkEdge, kDbgClkGate, kDbgClkDf, kDbgClkSlice, kDbgStrips, kDbgGateBatches, kDbgDfBatches, kDbgSliceBatches,
+    kDbgEdgeCands, kDbgFrames, kDbgLongFrames,
+    kCntAlloc = 32
 };
 
 struct DeviceTables {      // read-only, built once per context

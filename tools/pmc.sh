@@ -2,7 +2,7 @@
 # usage: tools/pmc.sh <tag> <counters...>   -- one PMC pass over tools/one_pass.py
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 tools/one_pass.py > gpurun_out/pmc_$tag.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 tools/one_pass.py frames > gpurun_out/pmc_$tag.log 2>&1
 python3 - "$tag" <<'PY'
 import csv, collections, glob, sys
 tag = sys.argv[1]
