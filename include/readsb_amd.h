@@ -50,7 +50,8 @@ enum {
  * (sdr_ifile.c:82-106, readsb.c:485-509, 538-540). */
 typedef struct rsb_config {
     int32_t input_format;      /* RSB_UC8 / RSB_SC16 / RSB_SC16Q11 */
-    int32_t dc_filter;         /* --dcfilter: not yet available on the GPU path -> RSB_EINVAL */
+    int32_t dc_filter;         /* --dcfilter (readsb.c:485-487): the DC-block IIR of convert.c:137-140 as a chunked scan; results
+                                  follow the reference within a tolerance, not bit for bit */
     int32_t fix_bits;          /* Modes.nfix_crc: 0 (--no-fix), 1 (--fix, default), 2 (--aggressive) */
     int32_t mode_ac;           /* --modeac */
     int32_t device;            /* HIP device ordinal */
@@ -150,6 +151,11 @@ int rsb_process(rsb_ctx *ctx, const void *iq_dev, uint64_t nsamples, void *strea
  * into a device buffer owned by the context first. */
 int rsb_process_host(rsb_ctx *ctx, const void *iq_host, uint64_t nsamples,
                      rsb_message *out, size_t cap, size_t *n_out);
+
+/* --dcfilter contexts only: the magnitudes the converter produced for the last collected batch (what iq_convert_fn
+ * would have written, convert.c:113-423) and, if block_means != NULL and the context runs Mode A/C, mean level / mean
+ * power of each of its 131072-sample blocks.  For checking the demodulators apart from the converter's tolerance. */
+int rsb_get_batch_magnitudes(rsb_ctx *ctx, uint16_t *mag_host, uint64_t nsamples, double *block_means);
 
 int rsb_get_stats(const rsb_ctx *ctx, rsb_stats *st);
 int rsb_get_timing(const rsb_ctx *ctx, rsb_timing *t);

@@ -818,7 +818,9 @@ static void demod2400AC(orc_ctx *c, const uint16_t *m, uint32_t mlen, uint64_t s
 
 /* ------------------------------------------------------------------ the sdr_ifile.c block loop (sdr_ifile.c:184-228) */
 
-size_t orc_run_stream(orc_ctx *c, const void *iq, uint64_t nsamples, orc_msg *out, size_t cap) {
+/* mags != NULL: the magnitudes (and block_means[2k], [2k+1] = mean level / power of block k) come from the caller
+ * instead of orc_convert -- the demodulators on somebody else's converter output */
+static size_t run_blocks(orc_ctx *c, const void *iq, const uint16_t *mags, const double *block_means, uint64_t nsamples, orc_msg *out, size_t cap) {
     const unsigned bps = (c->format == ORC_UC8) ? 2 : 4;
     uint16_t *buf[2];
     uint32_t length[2] = {0, 0};
@@ -845,7 +847,15 @@ size_t orc_run_stream(orc_ctx *c, const void *iq, uint64_t nsamples, orc_msg *ou
         }
         double mean_level = 0, mean_power = 0;
         length[cur] = (uint32_t) want;
-        orc_convert(c, (const uint8_t *) iq + pos * bps, &data[ORC_TRAILING], (unsigned) want, &mean_level, &mean_power);
+        if (mags) {
+            memcpy(&data[ORC_TRAILING], mags + pos, want * sizeof (uint16_t));
+            if (block_means) {
+                mean_level = block_means[2 * (pos / ORC_BLOCK_SAMPLES)];
+                mean_power = block_means[2 * (pos / ORC_BLOCK_SAMPLES) + 1];
+            }
+        } else {
+            orc_convert(c, (const uint8_t *) iq + pos * bps, &data[ORC_TRAILING], (unsigned) want, &mean_level, &mean_power);
+        }
         pos += want;
         demod2400(c, data, (uint32_t) want, sampleTimestamp);
         if (c->modeac)
@@ -856,6 +866,14 @@ size_t orc_run_stream(orc_ctx *c, const void *iq, uint64_t nsamples, orc_msg *ou
     free(buf[1]);
     c->out = NULL;
     return c->nout;
+}
+
+size_t orc_run_stream(orc_ctx *c, const void *iq, uint64_t nsamples, orc_msg *out, size_t cap) {
+    return run_blocks(c, iq, NULL, NULL, nsamples, out, cap);
+}
+
+size_t orc_run_mag_stream(orc_ctx *c, const uint16_t *mags, const double *block_means, uint64_t nsamples, orc_msg *out, size_t cap) {
+    return run_blocks(c, NULL, mags, block_means, nsamples, out, cap);
 }
 
 size_t orc_gated_candidates(orc_ctx *c, const void *iq, uint64_t nsamples, orc_candidate *out, size_t cap) {

@@ -64,6 +64,8 @@ void orc_reset(orc_ctx *c); /* filter, converter state, stats, stream position *
 /* whole-stream run in the sdr_ifile.c block model; returns number of messages (may exceed cap;
  * only the first cap are stored) */
 size_t orc_run_stream(orc_ctx *c, const void *iq, uint64_t nsamples, orc_msg *out, size_t cap);
+/* the same block loop on magnitudes the caller converted (block_means: mean level / power per 131072-sample block, or NULL) */
+size_t orc_run_mag_stream(orc_ctx *c, const uint16_t *mags, const double *block_means, uint64_t nsamples, orc_msg *out, size_t cap);
 void orc_get_stats(const orc_ctx *c, orc_stats *st);
 
 /* pieces, for unit tests */

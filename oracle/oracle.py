@@ -52,6 +52,8 @@ def _lib():
     lib.orc_reset.argtypes = [C.c_void_p]
     lib.orc_run_stream.restype = C.c_size_t
     lib.orc_run_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]
+    lib.orc_run_mag_stream.restype = C.c_size_t
+    lib.orc_run_mag_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]
     lib.orc_get_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.orc_convert.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
     lib.orc_checksum.restype = C.c_uint32
@@ -109,6 +111,19 @@ class Oracle:
         st = np.zeros(7, dtype=np.uint64)
         self.lib.orc_get_stats(self.h, st.ctypes.data)
         return out[:got].copy(), dict(zip(STAT_NAMES, (int(x) for x in st)))
+
+    def run_mag_stream(self, mags: np.ndarray, block_means: np.ndarray | None = None):
+        """The demodulators on magnitudes converted elsewhere (fresh filter): -> messages."""
+        mags = np.ascontiguousarray(mags, dtype=np.uint16)
+        bm = None if block_means is None else np.ascontiguousarray(block_means, dtype=np.float64)
+        cap = max(1024, mags.size // 100)
+        while True:
+            out = np.zeros(cap, dtype=REC_DTYPE)
+            self.reset()
+            got = self.lib.orc_run_mag_stream(self.h, mags.ctypes.data, bm.ctypes.data if bm is not None else None, mags.size, out.ctypes.data, cap)
+            if got <= cap:
+                return out[:got].copy()
+            cap = got
 
     def convert(self, iq: np.ndarray):
         raw = iq_bytes(iq)

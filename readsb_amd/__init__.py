@@ -66,6 +66,7 @@ SYMBOLS = {
     "rsb_process": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_process_host": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_get_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
+    "rsb_get_batch_magnitudes": (C.c_int, [_VP, _VP, C.c_uint64, _VP]),
     "rsb_get_timing": (C.c_int, [_VP, C.POINTER(Timing)]),
     "rsb_last_error": (C.c_char_p, [_VP]),
     "rsb_version": (C.c_char_p, []),
@@ -174,6 +175,13 @@ class Channel:
             if chunk.shape[0] < step:  # the reference also runs a final (possibly empty) block at EOF
                 break
         return np.concatenate(parts)
+
+    def batch_magnitudes(self, nsamples: int, want_means: bool = False):
+        """--dcfilter contexts: the converter's output for the last collected batch (and its per-block means)."""
+        mag = np.zeros(nsamples, dtype=np.uint16)
+        means = np.zeros(2 * ((nsamples + BLOCK - 1) // BLOCK), dtype=np.float64) if want_means else None
+        self._check(self.l.rsb_get_batch_magnitudes(self.h, mag.ctypes.data, nsamples, means.ctypes.data if want_means else None), "rsb_get_batch_magnitudes")
+        return mag, means
 
     def stats(self) -> dict:
         st = Stats()

@@ -95,6 +95,14 @@ int setup_device(rsb_ctx *c) {
     HIP_TRY(c, hipMalloc((void **)&c->d_block_sums, c->nblocks_cap * 2 * sizeof(uint64_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_block_means, c->nblocks_cap * 2 * sizeof(double)));
     HIP_TRY(c, hipMalloc(&c->d_carry, kTrailing * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->d_dc_state, sizeof(double2)));
+    HIP_TRY(c, hipMemset(c->d_dc_state, 0, sizeof(double2)));
+    if (c->cfg.dc_filter) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_magbuf, (size_t)nmax * sizeof(uint16_t) + 16));
+        c->dc_tiles_cap = (size_t)((nmax + kDcTileSamples - 1) / kDcTileSamples) + 1;
+        HIP_TRY(c, hipMalloc((void **)&c->d_dc_tile_sums, c->dc_tiles_cap * sizeof(double2)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_dc_tile_start, c->dc_tiles_cap * sizeof(double2)));
+    }
     c->host_replay_only = (c->cfg.flags & RSB_FLAG_HOST_REPLAY) != 0;
     if (!c->host_replay_only) {
         for (int w = 0; w < 2; ++w) HIP_TRY(c, hipMalloc((void **)&c->d_first_add[w], sizeof(uint32_t) << 24));
@@ -215,10 +223,6 @@ int rsb_create(const rsb_config *cfg, rsb_ctx **out) {
         std::fprintf(stderr, "no suitable converter for format=%d dc=%d\n", cfg->input_format, cfg->dc_filter);
         return RSB_EINVAL;
     }
-    if (cfg->dc_filter) {
-        std::fprintf(stderr, "readsb_amd: --dcfilter is not available on the GPU path yet\n");
-        return RSB_EINVAL;
-    }
     if (cfg->fix_bits < 0 || cfg->max_batch_samples == 0 || cfg->max_batch_samples > 0xfffff000ull) return RSB_EINVAL;
     rsb_ctx *c = new (std::nothrow) rsb_ctx(*cfg);
     if (!c) return RSB_ENOMEM;
@@ -238,7 +242,7 @@ void rsb_destroy(rsb_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1],
                     c->d_items, c->d_region_counts, c->d_skeys[0], c->d_skeys[1], c->d_sinfo[0], c->d_sinfo[1], c->d_sort_temp, c->d_surv_g, c->d_surv, c->d_ac, c->d_bitmap, c->d_counters, c->d_block_sums, c->d_carry,
-                    c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_new_adders, c->d_addr_upload, c->d_means, c->d_block_means};
+                    c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_new_adders, c->d_addr_upload, c->d_means, c->d_block_means, c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t ev : c->ev)
@@ -320,6 +324,15 @@ int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) 
         return RSB_EINVAL;
     }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (c->cfg.dc_filter) {
+        // --dcfilter: the chunked-scan converter writes the batch's magnitudes; the scan reads those (carry = the previous batch's last 326)
+        hipStream_t s = (hipStream_t)stream;
+        HIP_TRY(c, launch_convert_dc(c->cfg.input_format, iq_dev, c->d_magbuf, nsamples, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state,
+                                     c->run_ac ? c->d_block_means : nullptr, s));
+        BatchArgs a = c->batch_args(c->d_magbuf, nsamples, kFmtMag16);
+        if (c->run_ac) a.block_means = c->d_block_means;
+        return enqueue_batch(c, a, nsamples, s);
+    }
     return enqueue_batch(c, c->batch_args(iq_dev, nsamples, c->cfg.input_format), nsamples, (hipStream_t)stream);
 }
 
@@ -381,7 +394,7 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
     if (!c->block_mode && c->pending_n % kBlock == 0 && c->pending_n) {
         // the next batch's 326-sample overlap (sdr_ifile.c:199-201); only now, the kernels above still read the old one
-        const unsigned bps = (c->cfg.input_format == RSB_UC8) ? 2 : 4;
+        const unsigned bps = (a.fmt == kFmtUC8 || a.fmt == kFmtMag16) ? 2 : 4;
         HIP_TRY(c, hipMemcpyAsync(c->d_carry, (const char *)a.iq + (c->pending_n - kTrailing) * bps, (size_t)kTrailing * bps, hipMemcpyDeviceToDevice, s));
     }
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -501,6 +514,21 @@ int rsb_process_host(rsb_ctx *c, const void *iq_host, uint64_t nsamples, rsb_mes
     return rsb_process(c, c->d_stage ? c->d_stage : (const void *)c->d_carry, nsamples, nullptr, out, cap, n_out);
 }
 
+int rsb_get_batch_magnitudes(rsb_ctx *c, uint16_t *mag_host, uint64_t nsamples, double *block_means) {
+    if (!c || !mag_host) return RSB_EINVAL;
+    if (!c->cfg.dc_filter || c->pending || nsamples > c->pending_n) {
+        c->err = "rsb_get_batch_magnitudes: only after rsb_collect on a --dcfilter context, at most the batch's samples";
+        return RSB_ESTATE;
+    }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipMemcpy(mag_host, c->d_magbuf, (size_t)nsamples * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    if (block_means && c->run_ac) {
+        const size_t nblk = (size_t)((c->pending_n + kBlock - 1) / kBlock);
+        HIP_TRY(c, hipMemcpy(block_means, c->d_block_means, nblk * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return RSB_OK;
+}
+
 int rsb_get_stats(const rsb_ctx *c, rsb_stats *st) {
     if (!c || !st) return RSB_EINVAL;
     *st = const_cast<rsb_ctx *>(c)->replay.stats();
@@ -521,6 +549,30 @@ int rsb_convert_device(rsb_ctx *c, const void *iq_dev, void *mag_dev, uint64_t n
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const bool want = mean_level || mean_power;
+    if (c->cfg.dc_filter) {
+        // convert.c:113-162 / :164-213 / :374-423 as a chunked scan; the DC state lives in the context, as in struct converter_state
+        const size_t ntiles = (size_t)((nsamples + kDcTileSamples - 1) / kDcTileSamples) + 1, nblk = (size_t)((nsamples + kBlock - 1) / kBlock);
+        if (ntiles > c->dc_tiles_cap || nblk + 1 > c->nblocks_cap) {
+            c->err = "rsb_convert_device: nsamples exceeds rsb_config.max_batch_samples";
+            return RSB_EINVAL;
+        }
+        HIP_TRY(c, launch_convert_dc(c->cfg.input_format, iq_dev, (uint16_t *)mag_dev, nsamples, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state,
+                                     want ? c->d_block_means : nullptr, s));
+        if (want) {
+            std::vector<double> m(2 * nblk);
+            HIP_TRY(c, hipMemcpyAsync(m.data(), c->d_block_means, m.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            double lvl = 0, pwr = 0;  // one call = one mean (float sum / nsamples in the reference); blocks weighted by their length
+            for (size_t b = 0; b < nblk; ++b) {
+                const double len = (double)(b + 1 < nblk ? (uint64_t)kBlock : nsamples - (uint64_t)b * kBlock);
+                lvl += m[2 * b] * len;
+                pwr += m[2 * b + 1] * len;
+            }
+            if (mean_level) *mean_level = lvl / (double)nsamples;
+            if (mean_power) *mean_power = pwr / (double)nsamples;
+        }
+        return RSB_OK;
+    }
     const bool float_path = c->cfg.input_format != RSB_UC8;
     if (want && !c->d_sums) HIP_TRY(c, hipMalloc((void **)&c->d_sums, 2 * sizeof(uint64_t)));
     if (want && !float_path) HIP_TRY(c, hipMemsetAsync(c->d_sums, 0, 2 * sizeof(uint64_t), s));

@@ -65,6 +65,10 @@ struct rsb_ctx {
     std::vector<uint32_t> h_blk_counts, h_addrs;
     std::vector<uint2> h_new_adders;
     uint64_t *d_sums = nullptr;
+    // --dcfilter: magnitudes of the batch (the scan then reads them instead of IQ), the scan's tile arrays, the carried state
+    uint16_t *d_magbuf = nullptr;
+    double2 *d_dc_tile_sums = nullptr, *d_dc_tile_start = nullptr, *d_dc_state = nullptr;
+    size_t dc_tiles_cap = 0;
 
     // drop-in block mode (dropin.cpp): every call is one struct mag_buf -- magnitudes in, overlap included
     bool block_mode = false;

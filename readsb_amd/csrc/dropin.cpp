@@ -64,15 +64,16 @@ void convert_entry(void *iq_data, uint16_t *mag_data, unsigned nsamples, rsbd_co
 extern "C" rsbd_iq_convert_fn rsbd_init_converter(int format, double /*sample_rate: only the DC filter uses it (convert.c:480-488)*/, int filter_dc,
                                                   rsbd_converter_state **out_state) {
     if (out_state) *out_state = nullptr;
-    if (format < RSB_UC8 || format > RSB_SC16Q11 || filter_dc || !out_state) {
+    if (format < RSB_UC8 || format > RSB_SC16Q11 || !out_state) {
         std::fprintf(stderr, "no suitable converter for format=%d dc=%d\n", format, filter_dc);  // convert.c:460-464
         return nullptr;
     }
     rsb_config cfg;
     std::memset(&cfg, 0, sizeof(cfg));
     cfg.input_format = format;
+    cfg.dc_filter = filter_dc ? 1 : 0;
     cfg.fix_bits = 0;
-    cfg.max_batch_samples = 4096;  // the context is used for its tables only
+    cfg.max_batch_samples = filter_dc ? (2u << 20) : 4096;  // the context is used for its tables (and the DC filter's scan arrays) only
     cfg.flags = RSB_FLAG_HOST_REPLAY;
     rsb_ctx *ctx = nullptr;
     if (rsb_create(&cfg, &ctx) != RSB_OK) return nullptr;  // message already printed

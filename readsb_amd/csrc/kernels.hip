@@ -40,6 +40,7 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <cmath>
 #include <type_traits>
 
 namespace rsb {
@@ -681,8 +682,9 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     const uint64_t nstrips = (a.n + kTileShift + kStrip - 1) / kStrip;
     // The raw IQ of a strip is fetched one strip ahead into registers (8 x 16 bytes per lane and raw vector), so
     // the HBM latency of strip k + 1 hides behind the gate / slicing stages of strip k.
-    constexpr bool kVecFmt = (FMT == kFmtUC8 || FMT == kFmtSC16 || FMT == kFmtSC16Q11);
-    constexpr int kRawVecs = (FMT == kFmtUC8) ? 1 : 2;  // 16-byte loads per 8 samples
+    constexpr bool kVecFmt = true;
+    constexpr int kRawVecs = (FMT == kFmtUC8 || FMT == kFmtMag16) ? 1 : 2;  // 16-byte loads per 8 samples
+    constexpr int kBps = 2 * kRawVecs;                                       // bytes per sample
     uint4 pre[kPasses][kRawVecs];
     auto interior = [&](uint64_t strip) {  // wave-uniform: every chunk of the strip is aligned raw IQ (all strips but the first and the last few)
         const int64_t q = (int64_t)(strip * kStrip) - kTileShift - (int64_t)kTrailing;
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     auto prefetch = [&](uint64_t strip) {
         if (!interior(strip)) return;
         const int64_t q = (int64_t)(strip * kStrip) - kTileShift - (int64_t)kTrailing;
-        const uint4 *src0 = (const uint4 *)((const uint8_t *)a.iq + (FMT == kFmtUC8 ? 2 : 4) * q) + kRawVecs * (int)lane;
+        const uint4 *src0 = (const uint4 *)((const uint8_t *)a.iq + kBps * q) + kRawVecs * (int)lane;
 #pragma unroll
         for (int t = 0; t < kPasses; ++t)
 #pragma unroll
@@ -700,11 +702,12 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     auto direct_chunk = [&](int t) {
         if constexpr (FMT == kFmtUC8) {
             return uc8_chunk(pre[t][0], sh.lut);
-        } else if constexpr (kVecFmt) {
+        } else if constexpr (FMT == kFmtMag16) {
+            const uint4 x = pre[t][0];
+            return make_uint4(x.x ^ kBias2, x.y ^ kBias2, x.z ^ kBias2, x.w ^ kBias2);
+        } else {
             const uint4 x0 = pre[t][0], x1 = pre[t][kRawVecs - 1];
             return make_uint4(sc16_pair<FMT>(x0, 0), sc16_pair<FMT>(x0, 1), sc16_pair<FMT>(x1, 0), sc16_pair<FMT>(x1, 1));
-        } else {
-            return make_uint4(0, 0, 0, 0);
         }
     };
     const uint64_t strip_step = (uint64_t)gridDim.x * kScanWaves;
@@ -1193,97 +1196,165 @@ __global__ __launch_bounds__(kThreads) void k_filter_fill(uint32_t *t0, uint32_t
     if (i < n) t0[addrs[i]] = t1[addrs[i]] = 0;
 }
 
-// One wavefront per accepted message: re-slice the winning phase (lane G = bits 5G..5G+4), repair it
-// (crc.c:410-418), fill in the fields of mode_s.c:424-562 and the signal level of demod_2400.c:342-354.
+constexpr int kEmitWaves = 16;       // persistent workgroups, two per CU
+constexpr int kWinChunks = 39;       // 16-byte chunks of 8 samples that cover a 304-sample window at any alignment
+constexpr int kEmitDepth = 4;        // windows in flight per wavefront
+// One wavefront per 64 accepted messages: the lanes fetch the 64 items' metadata together, then the messages are
+// taken one by one -- re-slice the winning phase (lane G = bits 5G..5G+4), repair it (crc.c:410-418), fill in the
+// fields of mode_s.c:424-562 and the signal level of demod_2400.c:342-354 -- with the raw IQ of the next
+// kEmitDepth windows already in flight in registers.
 template <int FMT>
-__global__ __launch_bounds__(kThreads) void k_replay_emit(const BatchArgs a, const ReplayArgs r) {
+__global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs a, const ReplayArgs r) {
+    __shared__ __attribute__((aligned(16))) uint16_t lut[FMT == kFmtUC8 ? 16384 : 8];
     __shared__ uint32_t sbs[112];
-    __shared__ __attribute__((aligned(16))) uint16_t win[kThreads / 64][kHalo];
-    __shared__ uint32_t grp[kThreads / 64][28];
-    __shared__ __attribute__((aligned(8))) uint8_t rec[kThreads / 64][56];
+    __shared__ __attribute__((aligned(16))) uint16_t win[kEmitWaves][kWinChunks * 8];
+    __shared__ uint32_t grp[kEmitWaves][28];
+    __shared__ __attribute__((aligned(8))) uint8_t rec[kEmitWaves][56];
     if (threadIdx.x < 112) sbs[threadIdx.x] = a.tab.sbs[threadIdx.x];
+    if (FMT == kFmtUC8)
+        for (uint32_t i = threadIdx.x; i < 16384; i += 64 * kEmitWaves) {  // the scan kernel's folded table (uc8_addr)
+            const uint32_t ai = i & 127, aq = i >> 7;
+            lut[i ^ ((aq & 31) << 1)] = (uint16_t)(a.tab.uc8_lut[((128 + aq) << 8) | (128 + ai)] ^ kBias);
+        }
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t nacc = a.counters[kCntAccepted];
     if (nacc > r.out_cap) nacc = r.out_cap;
     uint32_t by_errors[3] = {0, 0, 0};
-    for (uint32_t mi = blockIdx.x * (kThreads / 64) + wave; mi < nacc; mi += gridDim.x * (kThreads / 64)) {
-        const uint32_t idx = r.acc_idx[mi];
-        const uint64_t key = r.keys[idx];
-        const uint32_t info = r.info[idx], score = r.acc[idx] - 1;
-        const uint32_t g = (uint32_t)(key >> 3), phase = (uint32_t)key & 7u, combo = item_combo(info);
-        const bool lng = !combo_is_short(combo);
-        const uint32_t nbits = lng ? 112 : 56, ngroups = lng ? 23 : 12;
-        wave_sync();
-        for (uint32_t k = lane; k < (uint32_t)kHalo; k += 64) win[wave][k] = (uint16_t)(stream_mag<FMT>(a, (int64_t)g + k) ^ kBias);
-        wave_sync();
-        uint32_t b = 0, syn = 0;
-        if (lane < ngroups) {
-            const RotSlicer rs(phase);
-            b = rs.group(win[wave], 19, (int)lane);
+    constexpr bool kVecFmt = (FMT == kFmtUC8 || FMT == kFmtSC16 || FMT == kFmtSC16Q11);
+    constexpr int kRawVecs = (FMT == kFmtUC8) ? 1 : 2;
+    const uint32_t nwaves = gridDim.x * kEmitWaves;
+    for (uint32_t base = (blockIdx.x * kEmitWaves + wave) * 64u; base < nacc; base += nwaves * 64u) {
+        const uint32_t count = min(64u, nacc - base);
+        // the 64 items' metadata, one per lane
+        uint32_t l_g = 0, l_phase = 0, l_info = 0, l_score = 0;
+        if (lane < count) {
+            const uint32_t idx = r.acc_idx[base + lane];
+            const uint64_t key = r.keys[idx];
+            l_g = (uint32_t)(key >> 3);
+            l_phase = (uint32_t)key & 7u;
+            l_info = r.info[idx];
+            l_score = r.acc[idx] - 1;
+        }
+        auto window_of = [&](uint32_t g, int64_t &qa) {  // can the window of S[g..g+304) be read as aligned raw IQ chunks from qa on?
+            const int64_t q0 = (int64_t)g - (int64_t)kTrailing;
+            qa = q0 & ~(int64_t)7;
+            return kVecFmt && a.iq_aligned && qa >= 0 && qa + 8 * kWinChunks <= (int64_t)a.n;
+        };
+        uint4 raw[kEmitDepth][kRawVecs];
+        auto issue = [&](int slot, uint32_t m) {  // message m of this group: its window's raw chunk for this lane
+            if (m >= count) return;
+            const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)l_g, (int)m);
+            int64_t qa;
+            if (window_of(g, qa) && lane < (uint32_t)kWinChunks) {
+                const uint4 *src = (const uint4 *)((const uint8_t *)a.iq + (FMT == kFmtUC8 ? 2 : 4) * (qa + 8 * (int64_t)lane));
 #pragma unroll
-            for (uint32_t j = 0; j < 5; ++j) {
-                const uint32_t k = 5 * lane + j;
-                if (k >= nbits) b &= ~(16u >> j);
-                else if ((b >> (4 - j)) & 1) syn ^= sbs[k + 112 - nbits];  // crc.c:59-64, the CRC is linear
+                for (int v = 0; v < kRawVecs; ++v) raw[slot][v] = src[v];
             }
-        }
-        if (lane < 28) grp[wave][lane] = b;
-        // demod_2400.c:345-351
-        const uint32_t signal_len = nbits * 12 / 5;
-        uint64_t pw = 0;
-        for (uint32_t k = lane; k < signal_len; k += 64) {
-            const uint64_t mag = win[wave][19 + k] ^ kBias;
-            pw += mag * mag;
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            syn ^= __shfl_xor(syn, off, 64);
-            pw += __shfl_xor(pw, off, 64);
-        }
-        wave_sync();
-        const uint32_t df = grp[wave][0];
-        // repair: DF11 on the syndrome without its IID bits (mode_s.c:475-489), DF17/18 on all of it (:508-518)
-        uint32_t fix = 0;
-        if (combo >= kComboDf11Iid0) {
-            const uint32_t s = (combo <= kComboDf11IidX + 1) ? (syn & 0xffff80u) : syn;
-            if (s) fix = diagnose(a.tab, lng ? 1 : 0, s);
-            if (fix == 0xffffffffu) fix = 0;  // cannot happen for an item the scan classified; keep the frame as sliced
-        }
-        const uint32_t nerr = fix & 0xffu;
-        if (lane < 14) {
-            uint32_t byte = 0;
-            if (lane < nbits / 8) {
-                const uint32_t G0 = (8 * lane) / 5, d = 8 * lane - 5 * G0;
-                const uint32_t v = (grp[wave][G0] << 10) | (grp[wave][G0 + 1] << 5) | grp[wave][G0 + 2];
-                byte = (v >> (7 - d)) & 0xffu;
-                for (uint32_t e = 0; e < nerr; ++e) {
-                    const uint32_t p = (fix >> (8 + 8 * e)) & 0xffu;
-                    if ((p >> 3) == lane) byte ^= 1u << (7 - (p & 7));
+        };
+#pragma unroll
+        for (int d = 0; d < kEmitDepth; ++d) issue(d, (uint32_t)d);
+        for (uint32_t m0 = 0; m0 < count; m0 += kEmitDepth) {
+#pragma unroll
+            for (int d = 0; d < kEmitDepth; ++d) {
+                const uint32_t m = m0 + d;
+                if (m >= count) break;
+                const uint32_t mi = base + m;
+                const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)l_g, (int)m), phase = (uint32_t)__builtin_amdgcn_readlane((int)l_phase, (int)m);
+                const uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)l_info, (int)m), score = (uint32_t)__builtin_amdgcn_readlane((int)l_score, (int)m);
+                const uint32_t combo = item_combo(info);
+                const bool lng = !combo_is_short(combo);
+                const uint32_t nbits = lng ? 112 : 56, ngroups = lng ? 23 : 12;
+                // the 304 magnitudes from S[g] on: win[wave][w0 + k]
+                int64_t qa;
+                const bool direct = window_of(g, qa);
+                const uint32_t w0 = direct ? (uint32_t)((int64_t)g - (int64_t)kTrailing - qa) : 0u;
+                wave_sync();
+                if (direct) {
+                    if (lane < (uint32_t)kWinChunks) {
+                        uint4 o;
+                        if constexpr (FMT == kFmtUC8) {
+                            o = uc8_chunk(raw[d][0], lut);
+                        } else if constexpr (kVecFmt) {
+                            const uint4 x0 = raw[d][0], x1 = raw[d][kRawVecs - 1];
+                            o = make_uint4(sc16_pair<FMT>(x0, 0), sc16_pair<FMT>(x0, 1), sc16_pair<FMT>(x1, 0), sc16_pair<FMT>(x1, 1));
+                        }
+                        ((uint4 *)win[wave])[lane] = o;
+                    }
+                } else {
+                    for (uint32_t k = lane; k < (uint32_t)kHalo; k += 64) win[wave][k] = (uint16_t)(stream_mag<FMT>(a, (int64_t)g + k) ^ kBias);
                 }
+                issue(d, m + kEmitDepth);  // this slot's registers are free again
+                wave_sync();
+                uint32_t b = 0, syn = 0;
+                if (lane < ngroups) {
+                    const RotSlicer rs(phase);
+                    b = rs.group(win[wave], (int)w0 + 19, (int)lane);
+#pragma unroll
+                    for (uint32_t j = 0; j < 5; ++j) {
+                        const uint32_t k = 5 * lane + j;
+                        if (k >= nbits) b &= ~(16u >> j);
+                        else if ((b >> (4 - j)) & 1) syn ^= sbs[k + 112 - nbits];  // crc.c:59-64, the CRC is linear
+                    }
+                }
+                if (lane < 28) grp[wave][lane] = b;
+                // demod_2400.c:345-351
+                const uint32_t signal_len = nbits * 12 / 5;
+                uint64_t pw = 0;
+                for (uint32_t k = lane; k < signal_len; k += 64) {
+                    const uint64_t mag = win[wave][w0 + 19 + k] ^ kBias;
+                    pw += mag * mag;
+                }
+                for (int off = 32; off > 0; off >>= 1) {
+                    syn ^= __shfl_xor(syn, off, 64);
+                    pw += __shfl_xor(pw, off, 64);
+                }
+                wave_sync();
+                const uint32_t df = grp[wave][0];
+                // repair: DF11 on the syndrome without its IID bits (mode_s.c:475-489), DF17/18 on all of it (:508-518)
+                uint32_t fix = 0;
+                if (combo >= kComboDf11Iid0) {
+                    const uint32_t sy = (combo <= kComboDf11IidX + 1) ? (syn & 0xffff80u) : syn;
+                    if (sy) fix = diagnose(a.tab, lng ? 1 : 0, sy);
+                    if (fix == 0xffffffffu) fix = 0;  // cannot happen for an item the scan classified; keep the frame as sliced
+                }
+                const uint32_t nerr = fix & 0xffu;
+                if (lane < 14) {
+                    uint32_t byte = 0;
+                    if (lane < nbits / 8) {
+                        const uint32_t G0 = (8 * lane) / 5, dd = 8 * lane - 5 * G0;
+                        const uint32_t v = (grp[wave][G0] << 10) | (grp[wave][G0 + 1] << 5) | grp[wave][G0 + 2];
+                        byte = (v >> (7 - dd)) & 0xffu;
+                        for (uint32_t e = 0; e < nerr; ++e) {
+                            const uint32_t p = (fix >> (8 + 8 * e)) & 0xffu;
+                            if ((p >> 3) == lane) byte ^= 1u << (7 - (p & 7));
+                        }
+                    }
+                    rec[wave][8 + lane] = (uint8_t)byte;
+                }
+                wave_sync();
+                if (lane == 0) {
+                    uint8_t *o = rec[wave];
+                    const uint64_t gg = r.g0 + g;
+                    *(uint64_t *)(o + 0) = 5 * gg + (8 + 56) * 12 + (phase + 4);  // demod_2400.c:320
+                    o[22] = (uint8_t)nbits;
+                    o[23] = (uint8_t)df;
+                    const bool parity_addr = combo <= kComboCommB;
+                    const uint32_t aa = ((uint32_t)o[9] << 16) | ((uint32_t)o[10] << 8) | o[11];
+                    *(uint32_t *)(o + 24) = syn;
+                    *(int32_t *)(o + 28) = (int32_t)nerr;
+                    *(uint32_t *)(o + 32) = parity_addr ? syn : aa;
+                    *(int32_t *)(o + 36) = (int32_t)score;
+                    *(int32_t *)(o + 40) = parity_addr ? 3 : (combo <= kComboDf11IidX + 1 ? 4 : 7);  // datasource_t
+                    *(uint32_t *)(o + 44) = (combo >= kComboDf11Iid0 && combo <= kComboDf11IidX + 1) ? (syn & 0x7fu) : 0u;
+                    const double signal_power = (double)pw / 65535.0 / 65535.0;
+                    *(double *)(o + 48) = signal_power / (double)signal_len;
+                }
+                wave_sync();
+                if (lane < 14) ((uint32_t *)&r.out[mi])[lane] = ((const uint32_t *)rec[wave])[lane];
+                ++by_errors[nerr < 3 ? nerr : 2];
             }
-            rec[wave][8 + lane] = (uint8_t)byte;
         }
-        wave_sync();
-        if (lane == 0) {
-            uint8_t *o = rec[wave];
-            const uint64_t gg = r.g0 + g;
-            *(uint64_t *)(o + 0) = 5 * gg + (8 + 56) * 12 + (phase + 4);  // demod_2400.c:320
-            o[22] = (uint8_t)nbits;
-            o[23] = (uint8_t)df;
-            const bool parity_addr = combo <= kComboCommB;
-            const uint32_t aa = ((uint32_t)o[9] << 16) | ((uint32_t)o[10] << 8) | o[11];
-            *(uint32_t *)(o + 24) = syn;
-            *(int32_t *)(o + 28) = (int32_t)nerr;
-            *(uint32_t *)(o + 32) = parity_addr ? syn : aa;
-            *(int32_t *)(o + 36) = (int32_t)score;
-            *(int32_t *)(o + 40) = parity_addr ? 3 : (combo <= kComboDf11IidX + 1 ? 4 : 7);  // datasource_t
-            *(uint32_t *)(o + 44) = (combo >= kComboDf11Iid0 && combo <= kComboDf11IidX + 1) ? (syn & 0x7fu) : 0u;
-            const double signal_power = (double)pw / 65535.0 / 65535.0;
-            *(double *)(o + 48) = signal_power / (double)signal_len;
-        }
-        wave_sync();
-        if (lane < 14) ((uint32_t *)&r.out[mi])[lane] = ((const uint32_t *)rec[wave])[lane];
-        ++by_errors[nerr < 3 ? nerr : 2];
     }
     if (lane == 0)
         for (int e = 0; e < 3; ++e)
@@ -1470,6 +1541,177 @@ __global__ __launch_bounds__(kThreads) void k_convert(const void *iq, uint16_t *
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// --dcfilter: the generic converters of convert.c:113-162 / :164-213 / :374-423.  The DC block is a first-order
+// recurrence z[n] = x[n] * dc_a + z[n-1] * dc_b per component with the state carried across calls (:152-153), which the
+// reference runs sample by sample in float32.  Here it is a chunked linear-recurrence scan: (1) every tile of 4096
+// samples is run from a zero state, 16 samples per thread, and reduced with the powers of dc_b to the tile's
+// contribution; (2) one workgroup scans the tiles; (3) every thread gets its exact starting state from its tile's and
+// runs its 16 samples like the reference does (float32, every product and sum rounded on its own).  The scan itself
+// is in double, so a thread's starting state differs from the reference's float32 history only in the last bits:
+// magnitudes agree to +-1 LSB (tests/test_gpu_parity.py states the tolerance), not bit for bit.
+
+constexpr int kDcPerThread = 16, kDcTile = kThreads * kDcPerThread;  // 4096 samples; kBlock % kDcTile == 0
+
+template <int FMT>
+__device__ __forceinline__ void dc_sample(const void *iq, uint64_t i, float &fI, float &fQ) {
+    if constexpr (FMT == kFmtUC8) {
+        const uchar2 v = ((const uchar2 *)iq)[i];
+        fI = ((float)v.x - 127.5f) / 127.5f;  // convert.c:131-132
+        fQ = ((float)v.y - 127.5f) / 127.5f;
+    } else {
+        const short2 v = ((const short2 *)iq)[i];
+        constexpr float scale = (FMT == kFmtSC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);  // exact: a power of two
+        fI = (float)v.x * scale;
+        fQ = (float)v.y * scale;
+    }
+}
+
+// inclusive scan over the workgroup's threads of the per-thread contributions: v[t] = sum_{u <= t} m^(t-u) * own[u], m = dc_b^16
+__device__ __forceinline__ double2 dc_block_scan(double2 own, double m, double2 *sh) {
+    const uint32_t t = threadIdx.x;
+    sh[t] = own;
+    __syncthreads();
+    double w = m;
+    for (uint32_t d = 1; d < (uint32_t)kThreads; d <<= 1) {
+        double2 add = make_double2(0, 0);
+        if (t >= d) add = sh[t - d];
+        __syncthreads();
+        if (t >= d) {
+            own.x += w * add.x;
+            own.y += w * add.y;
+            sh[t] = own;
+        }
+        __syncthreads();
+        w *= w;
+    }
+    return own;
+}
+
+// phase 1: the state each tile would end in when started from zero
+template <int FMT>
+__global__ __launch_bounds__(kThreads) void k_dc_tile_sums(const void *iq, uint64_t n, double dc_a, double dc_b, double2 *tile_sums) {
+    __shared__ double2 sh[kThreads];
+    const uint64_t first = (uint64_t)blockIdx.x * kDcTile + (uint64_t)threadIdx.x * kDcPerThread;
+    double zI = 0, zQ = 0;
+    for (int k = 0; k < kDcPerThread; ++k) {
+        float fI = 0, fQ = 0;  // beyond the end: zero input (the tile's sum is then not used by a later tile)
+        if (first + k < n) dc_sample<FMT>(iq, first + k, fI, fQ);
+        zI = (double)fI * dc_a + zI * dc_b;
+        zQ = (double)fQ * dc_a + zQ * dc_b;
+    }
+    double m16 = dc_b;
+    for (int k = 0; k < 4; ++k) m16 *= m16;  // dc_b^16
+    const double2 v = dc_block_scan(make_double2(zI, zQ), m16, sh);
+    if (threadIdx.x == kThreads - 1) tile_sums[blockIdx.x] = v;
+}
+
+// phase 2: state at the start of every tile; state[0] = the carried-in state, state[ntiles] = the state to carry out
+__global__ __launch_bounds__(1024) void k_dc_scan_tiles(const double2 *tile_sums, double2 *tile_start, uint32_t ntiles, const double2 *z_in, double dc_b) {
+    __shared__ double2 part[1024];
+    __shared__ double mpow[1024];
+    const uint32_t t = threadIdx.x, per = (ntiles + 1023) / 1024, lo = t * per, hi = min(ntiles, lo + per);
+    double mt = dc_b;
+    for (int k = 0; k < 12; ++k) mt *= mt;  // dc_b^4096: one tile
+    // this thread's run of tiles from a zero state, and the multiplier of the run
+    double zI = 0, zQ = 0, m = 1;
+    for (uint32_t i = lo; i < hi; ++i) {
+        zI = zI * mt + tile_sums[i].x;
+        zQ = zQ * mt + tile_sums[i].y;
+        m *= mt;
+    }
+    part[t] = make_double2(zI, zQ);
+    mpow[t] = m;
+    __syncthreads();
+    if (t == 0) {  // 1024 sequential steps: state at the start of every thread's run
+        double2 z = *z_in;
+        for (uint32_t u = 0; u < 1024; ++u) {
+            const double2 own = part[u];
+            part[u] = z;
+            z.x = z.x * mpow[u] + own.x;
+            z.y = z.y * mpow[u] + own.y;
+        }
+    }
+    __syncthreads();
+    double2 z = part[t];
+    for (uint32_t i = lo; i < hi; ++i) {
+        tile_start[i] = z;
+        z.x = z.x * mt + tile_sums[i].x;
+        z.y = z.y * mt + tile_sums[i].y;
+    }
+    if (hi == ntiles && lo < hi) tile_start[ntiles] = z;
+    if (ntiles == 0 && t == 0) tile_start[0] = *z_in;
+}
+
+// phase 3: magnitudes.  sums (optional): per 131072-sample block of this call, sum(mag) and sum(magsq) as doubles.
+template <int FMT>
+__global__ __launch_bounds__(kThreads) void k_convert_dc(const void *iq, uint16_t *mag, uint64_t n, float dc_a, float dc_b, const double2 *tile_start, double *sums,
+                                                         double2 *z_out) {
+    __shared__ double2 sh[kThreads];
+    const uint64_t first = (uint64_t)blockIdx.x * kDcTile + (uint64_t)threadIdx.x * kDcPerThread;
+    float fI[kDcPerThread], fQ[kDcPerThread];
+    double zI = 0, zQ = 0;
+#pragma unroll
+    for (int k = 0; k < kDcPerThread; ++k) {
+        fI[k] = fQ[k] = 0;
+        if (first + k < n) dc_sample<FMT>(iq, first + k, fI[k], fQ[k]);
+        zI = (double)fI[k] * (double)dc_a + zI * (double)dc_b;
+        zQ = (double)fQ[k] * (double)dc_a + zQ * (double)dc_b;
+    }
+    double m16 = (double)dc_b;
+    for (int k = 0; k < 4; ++k) m16 *= m16;
+    const double2 inc = dc_block_scan(make_double2(zI, zQ), m16, sh);  // state after this thread's samples, tile started from zero
+    // state before this thread's samples: the tile's start carried over 16 t samples, plus the threads before
+    const double2 z0 = tile_start[blockIdx.x];
+    const double carry = pow(m16, (double)threadIdx.x);
+    double2 before = make_double2(z0.x * carry, z0.y * carry);
+    if (threadIdx.x > 0) {
+        const double2 p = sh[threadIdx.x - 1];
+        before.x += p.x;
+        before.y += p.y;
+    }
+    (void)inc;
+    float z1_I = (float)before.x, z1_Q = (float)before.y;
+    double sl = 0, sp = 0;
+#pragma unroll
+    for (int k = 0; k < kDcPerThread; ++k) {
+        if (first + k >= n) break;
+        float xI = fI[k], xQ = fQ[k];
+        z1_I = xI * dc_a + z1_I * dc_b;  // convert.c:137-140
+        z1_Q = xQ * dc_a + z1_Q * dc_b;
+        xI -= z1_I;
+        xQ -= z1_Q;
+        float magsq = xI * xI + xQ * xQ;
+        if (magsq > 1.0f) magsq = 1.0f;
+        const float m = sqrtf(magsq);
+        mag[first + k] = (uint16_t)(m * 65535.0f + 0.5f);
+        sl += (double)m;
+        sp += (double)magsq;
+        if (first + k == n - 1) *z_out = make_double2((double)z1_I, (double)z1_Q);  // converter_state carried to the next call
+    }
+    if (sums) {
+        for (int off = 32; off > 0; off >>= 1) {
+            sl += __shfl_down(sl, off, 64);
+            sp += __shfl_down(sp, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0 && first < n) {
+            const uint64_t blk = first / kBlock;
+            atomicAdd(&sums[2 * blk], sl);
+            atomicAdd(&sums[2 * blk + 1], sp);
+        }
+    }
+}
+
+// block sums -> the converter's per-call means (float / unsigned division widened afterwards, convert.c:155-161)
+__global__ void k_dc_means(double *sums, uint64_t n, uint32_t nblocks) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint64_t start = (uint64_t)b * kBlock;
+    const double len = (double)((n - start < (uint64_t)kBlock) ? (n - start) : (uint64_t)kBlock);
+    sums[2 * b] /= len;
+    sums[2 * b + 1] /= len;
+}
+
 template <typename F>
 hipError_t by_format(int fmt, F &&f) {
     switch (fmt) {
@@ -1581,7 +1823,7 @@ hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *t
                                       (int)r.n_items, s);
     if (e != hipSuccess) return e;
     return by_format(a.fmt, [&](auto F) {
-        hipLaunchKernelGGL(k_replay_emit<decltype(F)::value>, dim3(2048), dim3(kThreads), 0, s, a, r);
+        hipLaunchKernelGGL(k_replay_emit<decltype(F)::value>, dim3(512), dim3(64 * kEmitWaves), 0, s, a, r);
         return hipGetLastError();
     });
 }
@@ -1612,6 +1854,30 @@ hipError_t launch_modeac(const BatchArgs &a, hipStream_t s) {
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_modeac<fmt>, dim3(tiles_of(a.n)), dim3(kThreads), 0, s, a);
         return hipGetLastError();
+    });
+}
+
+hipError_t launch_convert_dc(int fmt, const void *iq, uint16_t *mag, uint64_t n, double2 *tile_sums, double2 *tile_start, double2 *z_state, double *block_means,
+                             hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    // convert.c:480-488: dc_b = (float)exp(-2 pi / sample_rate), dc_a = (float)(1.0 - dc_b)
+    const float dc_b = (float)std::exp(-2.0 * 3.14159265358979323846 * 1.0 / 2400000.0);
+    const float dc_a = (float)(1.0 - (double)dc_b);
+    const uint32_t ntiles = (uint32_t)((n + kDcTile - 1) / kDcTile), nblocks = (uint32_t)((n + kBlock - 1) / kBlock);
+    return by_format(fmt, [&](auto F) {
+        constexpr int f = decltype(F)::value;
+        if constexpr (f == kFmtMag16) {
+            return hipErrorInvalidValue;
+        } else {
+            hipError_t e = hipSuccess;
+            if (block_means) e = hipMemsetAsync(block_means, 0, (size_t)nblocks * 2 * sizeof(double), s);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_dc_tile_sums<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, n, (double)dc_a, (double)dc_b, tile_sums);
+            hipLaunchKernelGGL(k_dc_scan_tiles, dim3(1), dim3(1024), 0, s, tile_sums, tile_start, ntiles, z_state, (double)dc_b);
+            hipLaunchKernelGGL(k_convert_dc<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, mag, n, dc_a, dc_b, tile_start, block_means, z_state);
+            if (block_means) hipLaunchKernelGGL(k_dc_means, dim3((nblocks + 255) / 256), dim3(256), 0, s, block_means, n, nblocks);
+            return hipGetLastError();
+        }
     });
 }
 

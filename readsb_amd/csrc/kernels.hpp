@@ -128,6 +128,12 @@ hipError_t launch_filter_rebuild(uint32_t *t0, uint32_t *t1, const uint32_t *add
 hipError_t launch_modeac(const BatchArgs &a, hipStream_t s);
 // SC16 / SC16Q11: per block of blk_len samples the reference's float32 running sums, as means (level, power)
 hipError_t launch_block_means_float(int fmt, const void *iq, uint64_t n, uint64_t blk_len, double *means, hipStream_t s);
+// --dcfilter converters (chunked linear-recurrence scan): n samples -> n magnitudes.  tile_sums / tile_start hold one double2 per 4096
+// samples (+1); z_state is the carried DC state (in: before sample 0, out: after sample n-1); block_means (optional) receives
+// the mean level / mean power of every 131072-sample block of the call
+constexpr int kDcTileSamples = 4096;
+hipError_t launch_convert_dc(int fmt, const void *iq, uint16_t *mag, uint64_t n, double2 *tile_sums, double2 *tile_start, double2 *z_state, double *block_means,
+                             hipStream_t s);
 hipError_t launch_convert(int fmt, const void *iq, uint16_t *mag, uint64_t n, const uint16_t *lut, uint64_t *sums, hipStream_t s);
 
 }  // namespace rsb

@@ -26,7 +26,7 @@ SCENARIOS = {
     "sc16q11": (Scenario(1_000_000, seed=5, fmt="SC16Q11"), dict(nfix=1, modeac=False)),
 }
 
-# --dcfilter scenarios (float IIR path; CPU oracle only for now)
+# --dcfilter scenarios (float IIR path: chunked scan on the GPU, compared under a stated tolerance)
 SCENARIOS.update({
     "uc8_dc": (Scenario(600_000, seed=6, dc_offset=0.03), dict(nfix=1, modeac=False, dc_filter=True)),
     "sc16_dc": (Scenario(600_000, seed=5, fmt="SC16", dc_offset=0.02), dict(nfix=1, modeac=False, dc_filter=True)),
@@ -34,8 +34,8 @@ SCENARIOS.update({
     "sc16_ac": (Scenario(600_000, seed=13, fmt="SC16", modeac_per_sec=300), dict(nfix=1, modeac=True)),
 })
 
-# scenarios the GPU path supports today
-GPU_SCENARIOS = [k for k, (sc, kw) in SCENARIOS.items() if not kw.get("dc_filter")]
+# scenarios the GPU path reproduces bit for bit
+GPU_SCENARIOS = [k for k, (sc, kw) in SCENARIOS.items() if not kw.get("dc_filter")]  # bit-exact ones; --dcfilter has its own test
 
 # converter known-answer cases: name -> (format, dc_filter, samples, samples per converter call)
 CONVERT_CASES = {

@@ -106,8 +106,8 @@ def test_create_validates_arguments():
     h = C.c_void_p()
     bad_fmt = readsb_amd.Config(7, 0, 1, 0, 0, 0, 1 << 20)
     assert l.rsb_create(C.byref(bad_fmt), C.byref(h)) == -1 and not h.value  # "no suitable converter", convert.c:460-464
-    dc = readsb_amd.Config(0, 1, 1, 0, 0, 0, 1 << 20)
-    assert l.rsb_create(C.byref(dc), C.byref(h)) == -1 and not h.value
+    neg_fix = readsb_amd.Config(0, 0, -1, 0, 0, 0, 1 << 20)
+    assert l.rsb_create(C.byref(neg_fix), C.byref(h)) == -1 and not h.value
     assert l.rsb_create(None, C.byref(h)) == -1
 
 
