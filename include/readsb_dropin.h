@@ -18,6 +18,7 @@
  *   demodulate2400            demod_2400.h:31, demod_2400.c:72-383 rsbd_demodulate2400
  *   demodulate2400AC          demod_2400.h:32, demod_2400.c:476-662 rsbd_demodulate2400AC
  *   icaoFilterInit/Add/Expire icao_filter.h,   icao_filter.c       rsbd_icaoFilter*
+ *   ifileOpen / ifileRun / ifileClose  sdr_ifile.c:115-272 (sdr.c:94)  rsbd_ifileOpen / rsbd_ifileRun / rsbd_ifileClose
  *
  * The reference keeps the demodulator's state in globals (Modes.*, the ICAO filter tables, the CRC
  * tables); a library cannot, so the two demodulator calls and the filter calls take a handle that
@@ -99,6 +100,25 @@ void rsbd_icaoFilterExpire(rsbd_modes *m); /* one flip; the reference's 60 s tim
  * demodulate2400AC reads mag->mean_level / mag->mean_power as the reference does (demod_2400.c:484-485). */
 void rsbd_demodulate2400(rsbd_modes *m, struct rsbd_mag_buf *mag, rsbd_use_message_fn use, void *user);
 void rsbd_demodulate2400AC(rsbd_modes *m, struct rsbd_mag_buf *mag, rsbd_use_message_fn use, void *user);
+
+/* ---- sdr_ifile.c: the "ifile" input driver -------------------------------------------------------- */
+
+/* What --device-type ifile --ifile <filename|-> --iformat <fmt> [--dcfilter] does on the reader thread
+ * (ifileOpen sdr_ifile.c:115-160, ifileRun :162-254) together with the main thread's demodulator loop
+ * (readsb.c:847-911), as one call: the file is read in batches of blocks_per_batch x 131072 samples (each read
+ * repeated until the batch is full or EOF, :209-223), every batch goes through the converter and both
+ * demodulators on the device with the 326-sample overlap, the DC state and the ICAO filter carried across, and
+ * the messages are handed to `use` in the reference's order.  --throttle (:230-238) has no counterpart.  */
+typedef struct rsbd_ifile rsbd_ifile;
+
+/* NULL + a message on stderr if the file cannot be opened (:119-127: "ifile: could not open %s: %s"), the format
+ * is unknown, or no HIP device is usable.  filename "-" = standard input. */
+rsbd_ifile *rsbd_ifileOpen(const char *filename, int input_format, int filter_dc, int nfix_crc, int mode_ac, int device, unsigned blocks_per_batch);
+/* Runs to EOF; returns the number of samples consumed (a trailing partial sample is dropped, as :225 does), or -1
+ * after a read or device error (message on stderr).  rsbd_ifileFilterAdd before the run = --show-only (readsb.c:249-250). */
+long long rsbd_ifileRun(rsbd_ifile *f, rsbd_use_message_fn use, void *user);
+void rsbd_ifileFilterAdd(rsbd_ifile *f, uint32_t addr);
+void rsbd_ifileClose(rsbd_ifile *f);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,11 @@
 // dropin.cpp -- include/readsb_dropin.h: the reference's per-block entry points on top of the kernels.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <cerrno>
+
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -239,3 +244,98 @@ void run_block(rsbd_modes *m, rsbd_mag_buf *mag, bool modes, bool modeac, rsbd_u
 
 extern "C" void rsbd_demodulate2400(rsbd_modes *m, rsbd_mag_buf *mag, rsbd_use_message_fn use, void *user) { run_block(m, mag, true, false, use, user); }
 extern "C" void rsbd_demodulate2400AC(rsbd_modes *m, rsbd_mag_buf *mag, rsbd_use_message_fn use, void *user) { run_block(m, mag, false, true, use, user); }
+
+// ================================================================================== sdr_ifile.c
+
+struct rsbd_ifile {
+    int fd = -1;
+    bool close_fd = false;
+    unsigned bps = 2;
+    uint64_t batch_samples = 0;
+    rsb_ctx *ctx = nullptr;
+    std::vector<uint8_t> readbuf;
+    std::vector<rsb_message> out;
+};
+
+extern "C" rsbd_ifile *rsbd_ifileOpen(const char *filename, int input_format, int filter_dc, int nfix_crc, int mode_ac, int device, unsigned blocks_per_batch) {
+    if (!filename) {
+        std::fprintf(stderr, "SDR type 'ifile' requires an --ifile argument\n");  // sdr_ifile.c:116-119
+        return nullptr;
+    }
+    rsbd_ifile *f = new (std::nothrow) rsbd_ifile;
+    if (!f) return nullptr;
+    if (std::strcmp(filename, "-") == 0) {
+        f->fd = STDIN_FILENO;  // sdr_ifile.c:121-123
+    } else if ((f->fd = open(filename, O_RDONLY)) < 0) {
+        std::fprintf(stderr, "ifile: could not open %s: %s\n", filename, std::strerror(errno));  // sdr_ifile.c:124-127
+        delete f;
+        return nullptr;
+    } else {
+        f->close_fd = true;
+    }
+    if (blocks_per_batch == 0) blocks_per_batch = 64;
+    f->bps = (input_format == RSB_UC8) ? 2 : 4;  // sdr_ifile.c:129-136
+    f->batch_samples = (uint64_t)blocks_per_batch * kBlock;
+    rsb_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    cfg.input_format = input_format;
+    cfg.dc_filter = filter_dc ? 1 : 0;
+    cfg.fix_bits = nfix_crc;
+    cfg.mode_ac = mode_ac ? 1 : 0;
+    cfg.device = device;
+    cfg.max_batch_samples = f->batch_samples;
+    if (rsb_create(&cfg, &f->ctx) != RSB_OK) {  // unknown format: "no suitable converter ..." (sdr_ifile.c:149-153)
+        rsbd_ifileClose(f);
+        return nullptr;
+    }
+    f->readbuf.resize((size_t)f->batch_samples * f->bps);
+    f->out.resize((size_t)(f->batch_samples / 32) + 4096);
+    return f;
+}
+
+extern "C" void rsbd_ifileFilterAdd(rsbd_ifile *f, uint32_t addr) {
+    if (f && f->ctx) (void)rsb_filter_add(f->ctx, addr);
+}
+
+extern "C" long long rsbd_ifileRun(rsbd_ifile *f, rsbd_use_message_fn use, void *user) {
+    if (!f || !f->ctx) return -1;
+    long long total = 0;
+    bool eof = false;
+    while (!eof) {
+        // sdr_ifile.c:209-223: read until the buffer is full or the file ends
+        size_t have = 0;
+        const size_t want = f->readbuf.size();
+        while (have < want) {
+            const ssize_t nread = read(f->fd, f->readbuf.data() + have, want - have);
+            if (nread < 0) {
+                if (errno == EINTR) continue;
+                std::fprintf(stderr, "ifile: error reading input file: %s\n", std::strerror(errno));
+                return -1;
+            }
+            if (nread == 0) {
+                eof = true;
+                break;
+            }
+            have += (size_t)nread;
+        }
+        const uint64_t nsamples = have / f->bps;  // sdr_ifile.c:225: whole samples only
+        // a short or empty batch ends the recording (the reference publishes a last, possibly empty, block too)
+        size_t n = 0;
+        int rc = rsb_process_host(f->ctx, f->readbuf.data(), nsamples, f->out.data(), f->out.size(), &n);
+        if (rc != RSB_OK) {
+            std::fprintf(stderr, "ifile: %s\n", rsb_last_error(f->ctx));
+            return -1;
+        }
+        if (use)
+            for (size_t i = 0; i < n; ++i) use(user, &f->out[i]);
+        total += (long long)nsamples;
+    }
+    return total;
+}
+
+extern "C" void rsbd_ifileClose(rsbd_ifile *f) {
+    if (!f) return;
+    if (f->close_fd && f->fd >= 0) close(f->fd);  // sdr_ifile.c:256-272
+    if (f->ctx) rsb_destroy(f->ctx);
+    delete f;
+}

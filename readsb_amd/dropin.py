@@ -36,6 +36,10 @@ SYMBOLS = {
     "rsbd_icaoFilterExpire": (None, [_VP]),
     "rsbd_demodulate2400": (None, [_VP, C.POINTER(MagBuf), USE_FN, _VP]),
     "rsbd_demodulate2400AC": (None, [_VP, C.POINTER(MagBuf), USE_FN, _VP]),
+    "rsbd_ifileOpen": (_VP, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
+    "rsbd_ifileRun": (C.c_longlong, [_VP, USE_FN, _VP]),
+    "rsbd_ifileFilterAdd": (None, [_VP, C.c_uint32]),
+    "rsbd_ifileClose": (None, [_VP]),
 }
 
 _bound = False
@@ -118,3 +122,19 @@ class Modes:
             self.h = None
 
     __del__ = close
+
+
+def run_ifile(path: str, fmt: int = 0, dc_filter: bool = False, nfix_crc: int = 1, mode_ac: bool = False, device: int = 0, blocks_per_batch: int = 64):
+    """--device-type ifile --ifile path: -> (samples consumed, messages)."""
+    l = dlib()
+    h = l.rsbd_ifileOpen(path.encode(), fmt, int(dc_filter), nfix_crc, int(mode_ac), device, blocks_per_batch)
+    if not h:
+        raise RuntimeError("rsbd_ifileOpen failed")
+    msgs = []
+    cb = USE_FN(lambda user, mm: msgs.append(np.ctypeslib.as_array(C.cast(mm, C.POINTER(C.c_uint8)), shape=(MSG_DTYPE.itemsize,)).copy()))
+    try:
+        n = l.rsbd_ifileRun(h, cb, None)
+    finally:
+        l.rsbd_ifileClose(h)
+    out = np.concatenate(msgs).view(MSG_DTYPE) if msgs else np.zeros(0, dtype=MSG_DTYPE)
+    return n, out

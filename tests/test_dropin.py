@@ -139,3 +139,25 @@ def test_block_demodulators_match_oracle(name, built):
     got = feed_blocks(modes, Oracle(fmt=sc.fmt), iq, kw["modeac"])
     assert first_mismatch(want, got.view(REC_DTYPE)) is None
     modes.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,blocks", [("dense_fix1_ac", 4), ("exact_2_blocks", 1), ("short_5000", 64), ("sc16", 3)])
+def test_ifile_driver_matches_oracle(name, blocks, built, tmp_path):
+    """sdr_ifile.c:115-254 + readsb.c:847-911 as one call: a recording on disk, read batch by batch (ragged end, a file
+    that is an exact multiple of the batch, a file shorter than one block), == the oracle's block loop on the same bytes."""
+    sc, kw = SCENARIOS[name]
+    iq = generate(sc)
+    path = tmp_path / "rec.iq"
+    raw = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+    (raw if name != "short_5000" else np.concatenate([raw, raw[:1]])).tofile(path)  # a trailing partial sample is dropped (sdr_ifile.c:225)
+    want, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
+    n, got = dropin.run_ifile(str(path), readsb_amd.FORMATS[sc.fmt], False, kw["nfix"], kw["modeac"], 0, blocks)
+    assert n == sc.n_samples
+    assert first_mismatch(want, got.view(REC_DTYPE)) is None
+
+
+def test_ifile_open_errors(capfd):
+    l = dropin.dlib()
+    assert not l.rsbd_ifileOpen(b"/nonexistent/file.iq", 0, 0, 1, 0, 0, 1)
+    assert "ifile: could not open /nonexistent/file.iq" in capfd.readouterr().err  # sdr_ifile.c:124-127
