@@ -79,22 +79,29 @@ int setup_device(rsb_ctx *c) {
     if (const char *e = std::getenv("RSB_STAGE_LIMIT")) c->stage_limit = std::atoi(e);  // ablation timing only
     if (const char *e = std::getenv("RSB_ABL")) c->debug_flags = std::atoi(e);
     if (const char *e = std::getenv("RSB_SCAN_GRID")) c->scan_grid = std::atoi(e);
-    HIP_TRY(c, hipMalloc((void **)&c->d_items, (size_t)c->item_cap * sizeof(ItemRec)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_region_counts, (size_t)c->scan_grid * kScanWavesPerGroup * sizeof(uint32_t)));
-    for (int w = 0; w < 2; ++w) {
-        HIP_TRY(c, hipMalloc((void **)&c->d_skeys[w], (size_t)c->surv_item_cap * sizeof(uint64_t)));
-        HIP_TRY(c, hipMalloc((void **)&c->d_sinfo[w], (size_t)c->surv_item_cap * sizeof(uint32_t)));
+    // --dcfilter keeps one magnitude buffer, which the replay of a batch still reads: one batch in flight there
+    c->nslots = c->cfg.dc_filter ? 1 : 2;
+    for (int k = 0; k < c->nslots; ++k) {
+        rsb_slot &b = c->slots[k];
+        HIP_TRY(c, hipMalloc((void **)&b.d_items, (size_t)c->item_cap * sizeof(ItemRec)));
+        HIP_TRY(c, hipMalloc((void **)&b.d_region_counts, (size_t)c->scan_grid * kScanWavesPerGroup * sizeof(uint32_t)));
+        for (int w = 0; w < 2; ++w) {
+            HIP_TRY(c, hipMalloc((void **)&b.d_skeys[w], (size_t)c->surv_item_cap * sizeof(uint64_t)));
+            HIP_TRY(c, hipMalloc((void **)&b.d_sinfo[w], (size_t)c->surv_item_cap * sizeof(uint32_t)));
+        }
+        HIP_TRY(c, hipMalloc((void **)&b.d_ac, (size_t)c->ac_cap * sizeof(AcCand)));
+        HIP_TRY(c, hipMalloc((void **)&b.d_counters, kCntAlloc * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&b.d_block_sums, c->nblocks_cap * 2 * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc((void **)&b.d_block_means, c->nblocks_cap * 2 * sizeof(double)));
+        for (hipEvent_t &ev : b.ev) HIP_TRY(c, hipEventCreate(&ev));
     }
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->replay_stream, hipStreamNonBlocking));
+    for (void *&p : c->d_carry) HIP_TRY(c, hipMalloc(&p, kTrailing * 4));
     c->sort_temp_bytes = sort_temp_bytes(c->surv_item_cap);
     HIP_TRY(c, hipMalloc(&c->d_sort_temp, c->sort_temp_bytes));
     HIP_TRY(c, hipMalloc((void **)&c->d_surv_g, (size_t)c->surv_item_cap * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_surv, (size_t)c->surv_cap * sizeof(Survivor)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_ac, (size_t)c->ac_cap * sizeof(AcCand)));
     HIP_TRY(c, hipMalloc((void **)&c->d_bitmap, (1u << 24) / 8));
-    HIP_TRY(c, hipMalloc((void **)&c->d_counters, kCntAlloc * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_block_sums, c->nblocks_cap * 2 * sizeof(uint64_t)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_block_means, c->nblocks_cap * 2 * sizeof(double)));
-    HIP_TRY(c, hipMalloc(&c->d_carry, kTrailing * 4));
     HIP_TRY(c, hipMalloc((void **)&c->d_dc_state, sizeof(double2)));
     HIP_TRY(c, hipMemset(c->d_dc_state, 0, sizeof(double2)));
     if (c->cfg.dc_filter) {
@@ -142,8 +149,8 @@ constexpr int kMaxReplayIterations = 16;
 
 // Returns 1 when the batch was replayed on the device (messages in c->d_surv as rsb_message records,
 // counters in cnt), 0 when the host path has to take it, < 0 on error.
-int device_replay(rsb_ctx *c, uint32_t n_items, hipStream_t s, uint32_t cnt[kCntCount]) {
-    const BatchArgs &a = c->pending_args;
+int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint32_t cnt[kCntCount]) {
+    const BatchArgs &a = b.pending_args;
     int rc;
     if (c->filter_dirty && (rc = mirror_filter(c, s)) != RSB_OK) return rc;
     ReplayArgs r;
@@ -154,12 +161,12 @@ int device_replay(rsb_ctx *c, uint32_t n_items, hipStream_t s, uint32_t cnt[kCnt
     r.acc = a.sinfo[c->sorted_buf ^ 1];
     r.acc_idx = (uint32_t *)a.skeys[c->sorted_buf ^ 1];
     r.blk_counts = c->d_blk_counts;
-    r.nblocks = (uint32_t)((c->pending_n + kBlock - 1) / kBlock);
+    r.nblocks = (uint32_t)((b.pending_n + kBlock - 1) / kBlock);
     r.new_adders = c->d_new_adders;
     r.new_adders_cap = rsb_ctx::kNewAddersCap;
     r.out = (rsb_message *)c->d_surv;
     r.out_cap = c->out_cap;
-    r.g0 = c->stream_pos;
+    r.g0 = b.g0;
     c->timing.replay_iterations = 0;
     std::memset(cnt + kCntChanged, 0, (kCntCount - kCntChanged) * sizeof(uint32_t));
     if (r.nblocks == 0) return 1;
@@ -169,7 +176,7 @@ int device_replay(rsb_ctx *c, uint32_t n_items, hipStream_t s, uint32_t cnt[kCnt
         r.t_next = c->d_first_add[c->first_cur ^ 1];
         HIP_TRY(c, launch_replay_iteration(a, r, s));
         uint32_t changed = 0;
-        HIP_TRY(c, hipMemcpyAsync(&changed, c->d_counters + kCntChanged, sizeof(changed), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(&changed, b.d_counters + kCntChanged, sizeof(changed), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         ++c->timing.replay_iterations;
         if (!changed) {
@@ -185,7 +192,7 @@ int device_replay(rsb_ctx *c, uint32_t n_items, hipStream_t s, uint32_t cnt[kCnt
         return 0;
     }
     HIP_TRY(c, launch_replay_finish(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
-    HIP_TRY(c, hipMemcpyAsync(cnt, c->d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(c->h_blk_counts.data(), c->d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     // The tables answer "is this address in the filter" as a set.  The reference's open-addressing table does
@@ -240,9 +247,19 @@ int rsb_create(const rsb_config *cfg, rsb_ctx **out) {
 void rsb_destroy(rsb_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
-    void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1],
-                    c->d_items, c->d_region_counts, c->d_skeys[0], c->d_skeys[1], c->d_sinfo[0], c->d_sinfo[1], c->d_sort_temp, c->d_surv_g, c->d_surv, c->d_ac, c->d_bitmap, c->d_counters, c->d_block_sums, c->d_carry,
-                    c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_new_adders, c->d_addr_upload, c->d_means, c->d_block_means, c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state};
+    void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
+                    c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_new_adders, c->d_addr_upload, c->d_means,
+                    c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state};
+    for (rsb_slot &b : c->slots) {
+        void *sp[] = {b.d_items, b.d_region_counts, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
+        for (void *p : sp)
+            if (p) (void)hipFree(p);
+        for (hipEvent_t ev : b.ev)
+            if (ev) (void)hipEventDestroy(ev);
+    }
+    if (c->replay_stream) (void)hipStreamDestroy(c->replay_stream);
+    for (void *p : c->d_carry)
+        if (p) (void)hipFree(p);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t ev : c->ev)
@@ -252,11 +269,17 @@ void rsb_destroy(rsb_ctx *c) {
 
 int rsb_reset(rsb_ctx *c) {
     if (!c) return RSB_EINVAL;
+    if (c->any_pending()) {  // a batch still in flight: wait for its kernels, then forget it
+        (void)hipSetDevice(c->cfg.device);
+        (void)hipDeviceSynchronize();
+    }
     c->replay.reset();
-    c->stream_pos = 0;
-    c->carry_valid = 0;
-    c->pending = false;
-    c->finished = false;
+    c->stream_pos = c->submit_pos = 0;
+    c->submitted = c->collected = 0;
+    for (rsb_slot &b : c->slots) b.pending = false;
+    for (int &v : c->carry_valid) v = 0;
+    c->finished = c->submit_finished = false;
+    c->last_n = 0;
     std::memset(&c->timing, 0, sizeof(c->timing));
     return reset_device(c);
 }
@@ -282,40 +305,53 @@ int rsb_filter_expire(rsb_ctx *c) {
     return RSB_OK;
 }
 
-static int enqueue_batch(rsb_ctx *c, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCntAlloc * sizeof(uint32_t), s));
-    HIP_TRY(c, hipMemsetAsync(c->d_region_counts, 0, (size_t)a.n_regions * sizeof(uint32_t), s));
-    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
+    HIP_TRY(c, hipMemsetAsync(b.d_counters, 0, kCntAlloc * sizeof(uint32_t), s));
+    HIP_TRY(c, hipMemsetAsync(b.d_region_counts, 0, (size_t)a.n_regions * sizeof(uint32_t), s));
+    HIP_TRY(c, hipEventRecord(b.ev[0], s));
     if (c->run_modes) HIP_TRY(c, launch_scan(a, c->scan_grid, s));
-    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    HIP_TRY(c, hipEventRecord(b.ev[1], s));
     if (c->run_modes) HIP_TRY(c, launch_prune(a, s));
-    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    HIP_TRY(c, hipEventRecord(b.ev[2], s));
     if (c->run_ac && nsamples) {
         const size_t nblk = (nsamples + kBlock - 1) / kBlock;
         BatchArgs ac = a;
         if (!ac.block_means && a.fmt != kFmtUC8) {
             // the float converters' block means (convert.c:226-262): exact only in sample order
-            HIP_TRY(c, launch_block_means_float(a.fmt, a.iq, nsamples, kBlock, c->d_block_means, s));
-            ac.block_means = c->d_block_means;
+            HIP_TRY(c, launch_block_means_float(a.fmt, a.iq, nsamples, kBlock, b.d_block_means, s));
+            ac.block_means = b.d_block_means;
         }
-        if (!ac.block_means) HIP_TRY(c, hipMemsetAsync(c->d_block_sums, 0, nblk * 2 * sizeof(uint64_t), s));
+        if (!ac.block_means) HIP_TRY(c, hipMemsetAsync(b.d_block_sums, 0, nblk * 2 * sizeof(uint64_t), s));
         HIP_TRY(c, launch_modeac(ac, s));
     }
-    HIP_TRY(c, hipEventRecord(c->ev[3], s));
-    c->pending = true;
-    c->pending_n = nsamples;
-    c->pending_stream = s;
-    c->pending_args = a;
+    if (!c->block_mode && nsamples % kBlock == 0 && nsamples) {
+        // the next batch's 326-sample overlap (sdr_ifile.c:199-201)
+        const unsigned bps = (a.fmt == kFmtUC8 || a.fmt == kFmtMag16) ? 2 : 4;
+        const unsigned k = (c->submitted + 1) % 3;
+        HIP_TRY(c, hipMemcpyAsync(c->d_carry[k], (const char *)a.iq + (nsamples - kTrailing) * bps, (size_t)kTrailing * bps, hipMemcpyDeviceToDevice, s));
+        c->carry_valid[k] = 1;
+    }
+    HIP_TRY(c, hipEventRecord(b.ev[3], s));
+    b.pending = true;
+    b.pending_n = nsamples;
+    b.pending_stream = s;
+    b.pending_args = a;
+    b.g0 = c->submit_pos;
+    ++c->submitted;
+    if (!c->block_mode) {
+        c->submit_pos += nsamples;
+        if (nsamples % kBlock != 0) c->submit_finished = true;
+    }
     return RSB_OK;
 }
 
 int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) {
     if (!c || (!iq_dev && nsamples) || c->block_mode) return RSB_EINVAL;
-    if (c->pending) {
-        c->err = "rsb_submit: previous batch not collected";
+    if (c->submitted - c->collected >= (unsigned)c->nslots) {
+        c->err = c->nslots == 1 ? "rsb_submit: previous batch not collected" : "rsb_submit: two batches already in flight: collect one first";
         return RSB_ESTATE;
     }
-    if (c->finished || c->stream_pos % kBlock != 0) {
+    if (c->submit_finished || c->submit_pos % kBlock != 0) {
         c->err = "rsb_submit: stream position is not a multiple of 131072 (only the last batch may be partial)";
         return RSB_ESTATE;
     }
@@ -324,35 +360,41 @@ int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) 
         return RSB_EINVAL;
     }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    rsb_slot &b = c->submit_slot();
+    hipStream_t s = (hipStream_t)stream;
     if (c->cfg.dc_filter) {
         // --dcfilter: the chunked-scan converter writes the batch's magnitudes; the scan reads those (carry = the previous batch's last 326)
-        hipStream_t s = (hipStream_t)stream;
         HIP_TRY(c, launch_convert_dc(c->cfg.input_format, iq_dev, c->d_magbuf, nsamples, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state,
-                                     c->run_ac ? c->d_block_means : nullptr, s));
-        BatchArgs a = c->batch_args(c->d_magbuf, nsamples, kFmtMag16);
-        if (c->run_ac) a.block_means = c->d_block_means;
-        return enqueue_batch(c, a, nsamples, s);
+                                     c->run_ac ? b.d_block_means : nullptr, s));
+        BatchArgs a = c->batch_args(b, c->d_magbuf, nsamples, kFmtMag16);
+        if (c->run_ac) a.block_means = b.d_block_means;
+        return enqueue_batch(c, b, a, nsamples, s);
     }
-    return enqueue_batch(c, c->batch_args(iq_dev, nsamples, c->cfg.input_format), nsamples, (hipStream_t)stream);
+    return enqueue_batch(c, b, c->batch_args(b, iq_dev, nsamples, c->cfg.input_format), nsamples, s);
 }
 
 int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     if (!c || (!out && cap)) return RSB_EINVAL;
     if (n_out) *n_out = 0;
-    if (!c->pending) {
+    if (!c->any_pending()) {
         c->err = "rsb_collect: nothing submitted";
         return RSB_ESTATE;
     }
-    c->pending = false;
+    rsb_slot &b = c->collect_slot();
+    b.pending = false;
+    ++c->collected;
+    c->last_n = b.pending_n;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    hipStream_t s = c->pending_stream;
+    // everything from here on runs on the context's own stream, behind this batch's scan and beside the next batch's
+    hipStream_t s = c->replay_stream;
+    HIP_TRY(c, hipStreamWaitEvent(s, b.ev[3], 0));
     uint32_t cnt[kCntCount];
-    HIP_TRY(c, hipMemcpyAsync(cnt, c->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
 #ifdef RSB_STAGE_CLOCKS
     {
         uint32_t dbg[kCntAlloc];
-        HIP_TRY(c, hipMemcpy(dbg, c->d_counters, sizeof(dbg), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(dbg, b.d_counters, sizeof(dbg), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "stage clocks (ticks/16 summed over waves): convert %u edge %u gate %u df %u slice %u | strips %u gate batches %u df batches %u slice batches %u | edge cands %u frames %u long %u gated %u\n",
                      dbg[kDbgClkConvert], dbg[kDbgClkEdge], dbg[kDbgClkGate], dbg[kDbgClkDf], dbg[kDbgClkSlice], dbg[kDbgStrips], dbg[kDbgGateBatches], dbg[kDbgDfBatches],
                      dbg[kDbgSliceBatches], dbg[kDbgEdgeCands], dbg[kDbgFrames], dbg[kDbgLongFrames], dbg[kCntGated]);
@@ -367,13 +409,13 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
         return RSB_EOVERFLOW;
     }
     const uint32_t n_items = cnt[kCntSurvItems];
-    const BatchArgs &a = c->pending_args;
-    HIP_TRY(c, hipEventRecord(c->ev[4], s));
+    const BatchArgs &a = b.pending_args;
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
     HIP_TRY(c, launch_sort(a, n_items, c->d_sort_temp, c->sort_temp_bytes, &c->sorted_buf, s));
-    HIP_TRY(c, hipEventRecord(c->ev[5], s));
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
 
     // the sequential half: on the device, unless asked otherwise or the device path declines the batch
-    const size_t nblocks = (size_t)((c->pending_n + kBlock - 1) / kBlock);
+    const size_t nblocks = (size_t)((b.pending_n + kBlock - 1) / kBlock);
     c->h_blk_counts.resize(nblocks + 1);
     int on_device = 0;
     c->timing.replay_iterations = 0;
@@ -382,21 +424,16 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
         std::memset(cnt + kCntChanged, 0, (kCntCount - kCntChanged) * sizeof(uint32_t));
         c->h_blk_counts.assign(nblocks + 1, 0);
     } else if (!c->host_replay_only && !a.emit_dead && !a.keep_all) {
-        on_device = device_replay(c, n_items, s, cnt);
+        on_device = device_replay(c, b, n_items, s, cnt);
         if (on_device < 0) return on_device;
     }
     uint32_t nsurv = 0;
     if (!on_device) {
         // kept items -> distinct offsets -> full candidate records for the host replay
         HIP_TRY(c, launch_unique_finalize(a, n_items, c->sorted_buf, c->d_sort_temp, c->sort_temp_bytes, s));
-        HIP_TRY(c, hipMemcpyAsync(&nsurv, c->d_counters + kCntSurvivors, sizeof(nsurv), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(&nsurv, b.d_counters + kCntSurvivors, sizeof(nsurv), hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(c, hipEventRecord(c->ev[6], s));
-    if (!c->block_mode && c->pending_n % kBlock == 0 && c->pending_n) {
-        // the next batch's 326-sample overlap (sdr_ifile.c:199-201); only now, the kernels above still read the old one
-        const unsigned bps = (a.fmt == kFmtUC8 || a.fmt == kFmtMag16) ? 2 : 4;
-        HIP_TRY(c, hipMemcpyAsync(c->d_carry, (const char *)a.iq + (c->pending_n - kTrailing) * bps, (size_t)kTrailing * bps, hipMemcpyDeviceToDevice, s));
-    }
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
     HIP_TRY(c, hipStreamSynchronize(s));
     if (!on_device && nsurv > c->surv_cap) {
         char buf[200];
@@ -417,7 +454,7 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     const auto t_copy = std::chrono::steady_clock::now();
     const uint32_t nac = cnt[kCntAc];
     c->h_ac.resize(nac);
-    if (nac) HIP_TRY(c, hipMemcpyAsync(c->h_ac.data(), c->d_ac, nac * sizeof(AcCand), hipMemcpyDeviceToHost, s));
+    if (nac) HIP_TRY(c, hipMemcpyAsync(c->h_ac.data(), b.d_ac, nac * sizeof(AcCand), hipMemcpyDeviceToHost, s));
     size_t n = 0;            // messages of this batch
     bool delivered = false;  // already in out[]
     rsb_stats &st = c->replay.stats();
@@ -445,12 +482,12 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     c->timing.copy_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_copy).count();
 
     float ms = 0;
-    (void)hipEventElapsedTime(&c->timing.scan_ms, c->ev[0], c->ev[1]);
-    (void)hipEventElapsedTime(&c->timing.prune_ms, c->ev[1], c->ev[2]);
-    (void)hipEventElapsedTime(&c->timing.modeac_ms, c->ev[2], c->ev[3]);
-    (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[3]);
-    (void)hipEventElapsedTime(&c->timing.sort_ms, c->ev[4], c->ev[5]);
-    (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]);
+    (void)hipEventElapsedTime(&c->timing.scan_ms, b.ev[0], b.ev[1]);
+    (void)hipEventElapsedTime(&c->timing.prune_ms, b.ev[1], b.ev[2]);
+    (void)hipEventElapsedTime(&c->timing.modeac_ms, b.ev[2], b.ev[3]);
+    (void)hipEventElapsedTime(&c->timing.total_ms, b.ev[0], b.ev[3]);
+    (void)hipEventElapsedTime(&c->timing.sort_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]);
     c->timing.device_replay_ms = on_device ? ms : 0.0f;
     if (!on_device) c->timing.prune_ms += ms;  // the candidate re-slice belongs to the prune stage of the host path
     c->timing.total_ms += c->timing.sort_ms + ms;
@@ -460,24 +497,23 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     if (!delivered) {
         c->msgs.clear();
         if (on_device)
-            c->replay.merge_modeac(c->stream_pos, c->dev_msgs, c->h_blk_counts.data(), nblocks, c->h_ac, c->msgs);
+            c->replay.merge_modeac(b.g0, c->dev_msgs, c->h_blk_counts.data(), nblocks, c->h_ac, c->msgs);
         else
-            c->replay.run_batch(c->stream_pos, c->h_surv, c->h_ac, c->msgs);
+            c->replay.run_batch(b.g0, c->h_surv, c->h_ac, c->msgs);
         n = c->msgs.size();
         if (!on_device && !c->host_replay_only) c->filter_dirty = true;  // the host moved the filter on
     }
     c->timing.replay_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
-    st.samples_processed += c->pending_n;
+    st.samples_processed += b.pending_n;
     st.gated_offsets += cnt[kCntGated];
     st.live_candidates += cnt[kCntItemsTotal];
     st.survivors += on_device ? cnt[kCntAccepted] : cnt[kCntSurvivors];
     st.modeac_candidates += cnt[kCntAc];
 
     if (!c->block_mode) {
-        c->stream_pos += c->pending_n;
-        if (c->pending_n % kBlock != 0) c->finished = true;
-        if (c->pending_n % kBlock == 0 && c->pending_n) c->carry_valid = 1;
+        c->stream_pos += b.pending_n;
+        if (b.pending_n % kBlock != 0) c->finished = true;
     }
 
     if (n_out) *n_out = n;
@@ -511,20 +547,20 @@ int rsb_process_host(rsb_ctx *c, const void *iq_host, uint64_t nsamples, rsb_mes
         c->stage_bytes = bytes;
     }
     if (bytes) HIP_TRY(c, hipMemcpy(c->d_stage, iq_host, bytes, hipMemcpyHostToDevice));
-    return rsb_process(c, c->d_stage ? c->d_stage : (const void *)c->d_carry, nsamples, nullptr, out, cap, n_out);
+    return rsb_process(c, c->d_stage ? c->d_stage : (const void *)c->d_carry[0], nsamples, nullptr, out, cap, n_out);
 }
 
 int rsb_get_batch_magnitudes(rsb_ctx *c, uint16_t *mag_host, uint64_t nsamples, double *block_means) {
     if (!c || !mag_host) return RSB_EINVAL;
-    if (!c->cfg.dc_filter || c->pending || nsamples > c->pending_n) {
+    if (!c->cfg.dc_filter || c->any_pending() || nsamples > c->last_n) {
         c->err = "rsb_get_batch_magnitudes: only after rsb_collect on a --dcfilter context, at most the batch's samples";
         return RSB_ESTATE;
     }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipMemcpy(mag_host, c->d_magbuf, (size_t)nsamples * sizeof(uint16_t), hipMemcpyDeviceToHost));
     if (block_means && c->run_ac) {
-        const size_t nblk = (size_t)((c->pending_n + kBlock - 1) / kBlock);
-        HIP_TRY(c, hipMemcpy(block_means, c->d_block_means, nblk * 2 * sizeof(double), hipMemcpyDeviceToHost));
+        const size_t nblk = (size_t)((c->last_n + kBlock - 1) / kBlock);
+        HIP_TRY(c, hipMemcpy(block_means, c->slots[0].d_block_means, nblk * 2 * sizeof(double), hipMemcpyDeviceToHost));
     }
     return RSB_OK;
 }
@@ -557,10 +593,10 @@ int rsb_convert_device(rsb_ctx *c, const void *iq_dev, void *mag_dev, uint64_t n
             return RSB_EINVAL;
         }
         HIP_TRY(c, launch_convert_dc(c->cfg.input_format, iq_dev, (uint16_t *)mag_dev, nsamples, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state,
-                                     want ? c->d_block_means : nullptr, s));
+                                     want ? c->slots[0].d_block_means : nullptr, s));
         if (want) {
             std::vector<double> m(2 * nblk);
-            HIP_TRY(c, hipMemcpyAsync(m.data(), c->d_block_means, m.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(m.data(), c->slots[0].d_block_means, m.size() * sizeof(double), hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
             double lvl = 0, pwr = 0;  // one call = one mean (float sum / nsamples in the reference); blocks weighted by their length
             for (size_t b = 0; b < nblk; ++b) {
@@ -676,16 +712,17 @@ int rsb_internal_create_block_ctx(int fix_bits, int device, unsigned max_length,
 
 int rsb_internal_submit_block(rsb_ctx *c, const uint16_t *mag_dev, unsigned length, bool modes, bool modeac, double mean_level, double mean_power) {
     if (!c || !c->block_mode || !mag_dev || length > c->cfg.max_batch_samples) return RSB_EINVAL;
-    if (c->pending) return RSB_ESTATE;
+    if (c->any_pending()) return RSB_ESTATE;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     c->run_modes = modes;
     c->run_ac = modeac;
-    BatchArgs a = c->batch_args(mag_dev + kTrailing, length, kFmtMag16, mag_dev);
+    rsb_slot &b = c->submit_slot();
+    BatchArgs a = c->batch_args(b, mag_dev + kTrailing, length, kFmtMag16, mag_dev);
     a.iq_aligned = 0;  // magnitudes go through the per-sample path of the scan kernel
     if (modeac) {
         const double means[2] = {mean_level, mean_power};
         HIP_TRY(c, hipMemcpy(c->d_means, means, sizeof(means), hipMemcpyHostToDevice));
         a.block_means = c->d_means;
     }
-    return enqueue_batch(c, a, length, nullptr);
+    return enqueue_batch(c, b, a, length, nullptr);
 }

@@ -10,6 +10,24 @@
 #include "kernels.hpp"
 #include "modes_host.hpp"
 
+// Everything one batch in flight owns: the scan kernel's outputs, its counters and events.  Two slots let the scan of
+// batch i + 1 run while batch i is sorted, replayed and copied out (rsb_submit may be called once more before rsb_collect).
+struct rsb_slot {
+    rsb::ItemRec *d_items = nullptr;
+    uint32_t *d_region_counts = nullptr;
+    uint64_t *d_skeys[2] = {nullptr, nullptr};
+    uint32_t *d_sinfo[2] = {nullptr, nullptr};
+    rsb::AcCand *d_ac = nullptr;
+    uint32_t *d_counters = nullptr;
+    uint64_t *d_block_sums = nullptr;
+    double *d_block_means = nullptr;  // SC16 / SC16Q11 with Mode A/C: the float converters' per-block means
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // scan start / end, prune end, Mode A/C end
+    bool pending = false;
+    uint64_t pending_n = 0, g0 = 0;   // samples of the batch, its stream position
+    hipStream_t pending_stream = nullptr;
+    rsb::BatchArgs pending_args;
+};
+
 struct rsb_ctx {
     explicit rsb_ctx(const rsb_config &c) : cfg(c), replay(c.fix_bits) {
         run_ac = c.mode_ac != 0;
@@ -29,13 +47,8 @@ struct rsb_ctx {
     uint32_t syn_mask[2] = {0, 0};
 
     // device work buffers
-    rsb::ItemRec *d_items = nullptr;
-    uint32_t *d_region_counts = nullptr;
-    uint64_t *d_skeys[2] = {nullptr, nullptr};
-    uint32_t *d_sinfo[2] = {nullptr, nullptr};
     uint32_t *d_surv_g = nullptr;
     rsb::Survivor *d_surv = nullptr;
-    rsb::AcCand *d_ac = nullptr;
     void *d_sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
     uint32_t item_cap = 0, surv_item_cap = 0, surv_cap = 0, ac_cap = 0;
@@ -44,11 +57,7 @@ struct rsb_ctx {
     int stage_limit = 99;
     int debug_flags = 0;
     uint32_t *d_bitmap = nullptr;
-    uint32_t *d_counters = nullptr;
-    uint64_t *d_block_sums = nullptr;
-    double *d_block_means = nullptr;  // SC16 / SC16Q11 with Mode A/C: the float converters' per-block means
     size_t nblocks_cap = 0;
-    void *d_carry = nullptr;
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
     uint16_t *d_mag = nullptr;  // drop-in block path
@@ -76,26 +85,35 @@ struct rsb_ctx {
     double *d_means = nullptr;
 
     // stream state
-    uint64_t stream_pos = 0;
-    int carry_valid = 0;
-    bool pending = false, finished = false;
-    uint64_t pending_n = 0;
-    hipStream_t pending_stream = nullptr;
-    rsb::BatchArgs pending_args;
+    rsb_slot slots[2];
+    // the 326 samples before batch k (the tail of batch k - 1, input format) live in d_carry[k % 3]: written when batch k - 1 is
+    // submitted, read by the scan and the replay of batch k, free again once batch k is collected
+    void *d_carry[3] = {nullptr, nullptr, nullptr};
+    int carry_valid[3] = {0, 0, 0};
+    int nslots = 1;                   // 2 unless --dcfilter (one magnitude buffer) or block mode
+    unsigned submitted = 0, collected = 0;  // batches so far: slot = count % nslots; submitted - collected <= nslots
+    rsb_slot &submit_slot() { return slots[submitted % nslots]; }
+    rsb_slot &collect_slot() { return slots[collected % nslots]; }
+    bool any_pending() const { return submitted != collected; }
+    uint64_t last_n = 0;              // samples of the last collected batch
+    hipStream_t replay_stream = nullptr;  // sort / replay / copy-out run here, behind the batch's scan (event) and beside the next one's
+    uint64_t stream_pos = 0;          // of the next batch to collect
+    uint64_t submit_pos = 0;          // of the next batch to submit
+    bool finished = false, submit_finished = false;
 
-    hipEvent_t ev[8];
+    hipEvent_t ev[4];                 // collect side: sort start / end, replay end
     rsb_timing timing;
     std::string err;
     std::vector<rsb::Survivor> h_surv;
     std::vector<rsb::AcCand> h_ac;
     std::vector<rsb_message> msgs, dev_msgs;
 
-    rsb::BatchArgs batch_args(const void *iq, uint64_t n, int fmt, const void *carry = nullptr) const {
+    rsb::BatchArgs batch_args(const rsb_slot &b, const void *iq, uint64_t n, int fmt, const void *carry = nullptr) const {
         rsb::BatchArgs a;
         std::memset(&a, 0, sizeof(a));
         a.iq = iq;
-        a.carry = carry ? carry : d_carry;
-        a.carry_valid = carry ? 1 : carry_valid;
+        a.carry = carry ? carry : d_carry[submitted % 3];
+        a.carry_valid = carry ? 1 : carry_valid[submitted % 3];
         a.fmt = fmt;
         a.n = n;
         a.tab.uc8_lut = d_lut;
@@ -108,7 +126,7 @@ struct rsb_ctx {
         }
         a.tab.nfix = cfg.fix_bits;
         a.iq_aligned = ((uintptr_t)iq % 16 == 0) ? 1 : 0;
-        a.items = d_items;
+        a.items = b.d_items;
         {
             // one item region per wavefront that will actually run (launch_scan shrinks the grid for small batches)
             const uint64_t nstrips = (n + 2 + rsb::kScanStrip - 1) / rsb::kScanStrip, need = (nstrips + rsb::kScanWavesPerGroup - 1) / rsb::kScanWavesPerGroup;
@@ -117,20 +135,20 @@ struct rsb_ctx {
         }
         a.shared_cap = item_cap / 16;
         a.item_region = (item_cap - a.shared_cap) / a.n_regions;
-        a.region_counts = d_region_counts;
+        a.region_counts = b.d_region_counts;
         a.surv_item_cap = surv_item_cap;
         for (int w = 0; w < 2; ++w) {
-            a.skeys[w] = d_skeys[w];
-            a.sinfo[w] = d_sinfo[w];
+            a.skeys[w] = b.d_skeys[w];
+            a.sinfo[w] = b.d_sinfo[w];
         }
         a.surv_g = d_surv_g;
         a.survivors = d_surv;
         a.surv_cap = surv_cap;
-        a.ac = d_ac;
+        a.ac = b.d_ac;
         a.ac_cap = ac_cap;
         a.adder_bitmap = d_bitmap;
-        a.counters = d_counters;
-        a.block_sums = d_block_sums;
+        a.counters = b.d_counters;
+        a.block_sums = b.d_block_sums;
         a.block_means = nullptr;
         a.emit_dead = 0;
         a.keep_all = 0;
