@@ -607,8 +607,8 @@ __device__ __forceinline__ lds_dword *frame_window(const uint16_t *m, uint32_t e
     return (lds_dword *)(uintptr_t)A;
 }
 
-__device__ __forceinline__ void load_coefs(const ScanShared &sh, uint32_t e0, uint32_t phase, uint32_t (&c)[15]) {
-    const uint4 *row = (const uint4 *)sh.coef[(e0 & 1u) * 5u + phase];
+__device__ __forceinline__ void load_coefs(const uint32_t (*coef)[16], uint32_t e0, uint32_t phase, uint32_t (&c)[15]) {
+    const uint4 *row = (const uint4 *)coef[(e0 & 1u) * 5u + phase];
     const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
     c[0] = r0.x; c[1] = r0.y; c[2] = r0.z; c[3] = r0.w; c[4] = r1.x; c[5] = r1.y; c[6] = r1.z; c[7] = r1.w;
     c[8] = r2.x; c[9] = r2.y; c[10] = r2.z; c[11] = r2.w; c[12] = r3.x; c[13] = r3.y; c[14] = r3.z;
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 j = W.gq[cand];
                 const uint32_t e0 = j + 19;
                 uint32_t c[15], D[8];
-                load_coefs(sh, e0, phase, c);
+                load_coefs(sh.coef, e0, phase, c);
                 lds_dword *mw = frame_window(W.m, e0);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) D[k] = mw[k];
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             DBG_COUNT(3, 1) DBG_COUNT(6, (uint32_t)__popcll(__ballot(lng)))
             const uint32_t e0 = j + 19;
             uint32_t c[15], D[8], N[6];
-            load_coefs(sh, e0, phase, c);
+            load_coefs(sh.coef, e0, phase, c);
             uint32_t A = (uint32_t)(uintptr_t)W.m + ((e0 >> 1) << 2);  // LDS byte address of the window's first dword
             uint32_t T = (uint32_t)(uintptr_t)sh.gsyn + 4u * (lng ? kGsynLong : kGsynShort);  // ... of this group's syndrome row
             {
@@ -1196,165 +1196,209 @@ __global__ __launch_bounds__(kThreads) void k_filter_fill(uint32_t *t0, uint32_t
     if (i < n) t0[addrs[i]] = t1[addrs[i]] = 0;
 }
 
-constexpr int kEmitWaves = 16;       // persistent workgroups, two per CU
-constexpr int kWinChunks = 39;       // 16-byte chunks of 8 samples that cover a 304-sample window at any alignment
-constexpr int kEmitDepth = 4;        // windows in flight per wavefront
-// One wavefront per 64 accepted messages: the lanes fetch the 64 items' metadata together, then the messages are
-// taken one by one -- re-slice the winning phase (lane G = bits 5G..5G+4), repair it (crc.c:410-418), fill in the
-// fields of mode_s.c:424-562 and the signal level of demod_2400.c:342-354 -- with the raw IQ of the next
-// kEmitDepth windows already in flight in registers.
+// One LANE per accepted message: the lane streams the raw IQ from the dword that holds S[g + 19] (16-byte loads at
+// 4-byte alignment, a few in flight), converts it in registers -- every row of two magnitudes sits at a fixed place in
+// the instruction stream, so no LDS window is needed -- re-slices the winning phase with the scan kernel's per-lane
+// coefficient slicer, repairs it (crc.c:410-418), fills in the fields of mode_s.c:424-562 and the signal level of
+// demod_2400.c:342-354, and writes its 56-byte record.  LDS holds only the tables: 16 wavefronts per CU.
+constexpr int kEmitWaves = 16;
+constexpr int kEmitTrios = 12;       // 3 chunks = 12 rows (24 samples) = 2 groups of five bits per step; 24 groups >= 23
+
+struct __attribute__((aligned(16))) EmitShared {
+    uint16_t lut[16384];
+    uint32_t coef[10][16];
+    uint32_t gsyn[(12 + 24) * 32];  // + one zero row: the 24th step
+};
+
+typedef uint4 __attribute__((aligned(4))) uint4_a4;
+
 template <int FMT>
 __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs a, const ReplayArgs r) {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[FMT == kFmtUC8 ? 16384 : 8];
-    __shared__ uint32_t sbs[112];
-    __shared__ __attribute__((aligned(16))) uint16_t win[kEmitWaves][kWinChunks * 8];
-    __shared__ uint32_t grp[kEmitWaves][28];
-    __shared__ __attribute__((aligned(8))) uint8_t rec[kEmitWaves][56];
-    if (threadIdx.x < 112) sbs[threadIdx.x] = a.tab.sbs[threadIdx.x];
+    __shared__ EmitShared sh;
+    constexpr uint32_t kT = 64 * kEmitWaves;
     if (FMT == kFmtUC8)
-        for (uint32_t i = threadIdx.x; i < 16384; i += 64 * kEmitWaves) {  // the scan kernel's folded table (uc8_addr)
+        for (uint32_t i = threadIdx.x; i < 16384; i += kT) {  // the scan kernel's folded table (uc8_addr)
             const uint32_t ai = i & 127, aq = i >> 7;
-            lut[i ^ ((aq & 31) << 1)] = (uint16_t)(a.tab.uc8_lut[((128 + aq) << 8) | (128 + ai)] ^ kBias);
+            sh.lut[i ^ ((aq & 31) << 1)] = (uint16_t)(a.tab.uc8_lut[((128 + aq) << 8) | (128 + ai)] ^ kBias);
         }
+    for (uint32_t i = threadIdx.x; i < 160; i += kT) {
+        const uint32_t row = i >> 4, e = i & 15;
+        sh.coef[row][e] = e < 15 ? coef_entry((int)(row / 5), (int)(row % 5), (int)(e / 3), (int)(e % 3)) : 0u;
+    }
+    for (uint32_t i = threadIdx.x; i < (12 + 24) * 32; i += kT) {  // crc.c:59-64, as in the scan kernel
+        const bool lng = i >= (uint32_t)kGsynLong;
+        const uint32_t e = lng ? i - kGsynLong : i, G = e >> 5, v = e & 31, nbits = lng ? 112 : 56;
+        uint32_t x = 0;
+        for (uint32_t j = 0; j < 5; ++j) {
+            const uint32_t k = 5 * G + j;
+            if (((v >> (4 - j)) & 1) && k < nbits) x ^= a.tab.sbs[k + 112 - nbits];
+        }
+        sh.gsyn[i] = x;
+    }
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63;
     uint32_t nacc = a.counters[kCntAccepted];
     if (nacc > r.out_cap) nacc = r.out_cap;
-    uint32_t by_errors[3] = {0, 0, 0};
-    constexpr bool kVecFmt = (FMT == kFmtUC8 || FMT == kFmtSC16 || FMT == kFmtSC16Q11);
-    constexpr int kRawVecs = (FMT == kFmtUC8) ? 1 : 2;
-    const uint32_t nwaves = gridDim.x * kEmitWaves;
-    for (uint32_t base = (blockIdx.x * kEmitWaves + wave) * 64u; base < nacc; base += nwaves * 64u) {
-        const uint32_t count = min(64u, nacc - base);
-        // the 64 items' metadata, one per lane
-        uint32_t l_g = 0, l_phase = 0, l_info = 0, l_score = 0;
-        if (lane < count) {
-            const uint32_t idx = r.acc_idx[base + lane];
+    uint32_t by_errors[3] = {0, 0, 0};  // wave-uniform
+    constexpr int kRawVecs = (FMT == kFmtUC8 || FMT == kFmtMag16) ? 1 : 2;
+    constexpr int kBps = 2 * kRawVecs;
+    const uint32_t nthreads = gridDim.x * kT;
+    for (uint32_t base = (blockIdx.x * kT + threadIdx.x) & ~63u; base < nacc; base += nthreads) {
+        const uint32_t mi = base + lane;
+        const bool valid = mi < nacc;
+        uint32_t g = 0, phase = 0, info = kComboDf17 << 27, score = 0;
+        if (valid) {
+            const uint32_t idx = r.acc_idx[mi];
             const uint64_t key = r.keys[idx];
-            l_g = (uint32_t)(key >> 3);
-            l_phase = (uint32_t)key & 7u;
-            l_info = r.info[idx];
-            l_score = r.acc[idx] - 1;
+            g = (uint32_t)(key >> 3);
+            phase = (uint32_t)key & 7u;
+            info = r.info[idx];
+            score = r.acc[idx] - 1;
         }
-        auto window_of = [&](uint32_t g, int64_t &qa) {  // can the window of S[g..g+304) be read as aligned raw IQ chunks from qa on?
-            const int64_t q0 = (int64_t)g - (int64_t)kTrailing;
-            qa = q0 & ~(int64_t)7;
-            return kVecFmt && a.iq_aligned && qa >= 0 && qa + 8 * kWinChunks <= (int64_t)a.n;
-        };
-        uint4 raw[kEmitDepth][kRawVecs];
-        auto issue = [&](int slot, uint32_t m) {  // message m of this group: its window's raw chunk for this lane
-            if (m >= count) return;
-            const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)l_g, (int)m);
-            int64_t qa;
-            if (window_of(g, qa) && lane < (uint32_t)kWinChunks) {
-                const uint4 *src = (const uint4 *)((const uint8_t *)a.iq + (FMT == kFmtUC8 ? 2 : 4) * (qa + 8 * (int64_t)lane));
+        const uint32_t combo = item_combo(info);
+        const bool lng = !combo_is_short(combo);
+        const uint32_t nbits = lng ? 112 : 56;
+        const bool any_long = __ballot(lng) != 0;
+        const int ntrios = any_long ? kEmitTrios : 8;  // wave-uniform and even: 56-bit frames end in group 11 (rows 66..73), their power sum in row 67
+        // row 0 = the dword that holds S[g + 19] (an even stream index); par = which half of it
+        const int64_t e0 = (int64_t)g + 19 - (int64_t)kTrailing;  // index into iq of the first data sample (may be < 0: the overlap)
+        const uint32_t par = (uint32_t)e0 & 1u;
+        const int64_t sd = e0 - (int64_t)par;
+        const bool direct = a.iq_aligned && sd >= 0 && sd + 24 * ntrios <= (int64_t)a.n;
+        const uint4_a4 *src = (const uint4_a4 *)((const uint8_t *)a.iq + kBps * sd);
+        uint4 raw[2][3][kRawVecs];  // two trios in flight
+        auto issue = [&](int slot, int t) {
+            if (!direct) return;
 #pragma unroll
-                for (int v = 0; v < kRawVecs; ++v) raw[slot][v] = src[v];
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int v = 0; v < kRawVecs; ++v) raw[slot][k][v] = src[kRawVecs * (3 * t + k) + v];
+        };
+        auto rows_of = [&](int slot, int t, uint32_t (&R)[12]) {  // 24 samples from row 12 t on -> 12 rows of biased magnitude pairs
+            if (direct) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    uint4 o;
+                    if constexpr (FMT == kFmtUC8) {
+                        o = uc8_chunk(raw[slot][k][0], sh.lut);
+                    } else if constexpr (FMT == kFmtMag16) {
+                        const uint4 x = raw[slot][k][0];
+                        o = make_uint4(x.x ^ kBias2, x.y ^ kBias2, x.z ^ kBias2, x.w ^ kBias2);
+                    } else {
+                        const uint4 x0 = raw[slot][k][0], x1 = raw[slot][k][kRawVecs - 1];
+                        o = make_uint4(sc16_pair<FMT>(x0, 0), sc16_pair<FMT>(x0, 1), sc16_pair<FMT>(x1, 0), sc16_pair<FMT>(x1, 1));
+                    }
+                    R[4 * k] = o.x;
+                    R[4 * k + 1] = o.y;
+                    R[4 * k + 2] = o.z;
+                    R[4 * k + 3] = o.w;
+                }
+            } else {  // near the ends of the stream, or unaligned input: sample by sample
+                const int64_t s = (int64_t)g + 19 - (int64_t)par + 24 * t;  // S index of the trio's first sample
+                for (int k = 0; k < 12; ++k)
+                    R[k] = ((stream_mag<FMT>(a, s + 2 * k) ^ kBias) & 0xffffu) | ((stream_mag<FMT>(a, s + 2 * k + 1) ^ kBias) << 16);
             }
         };
+        uint32_t c[15];
+        load_coefs(sh.coef, par, phase, c);
+        const uint32_t *gs = sh.gsyn + (lng ? kGsynLong : kGsynShort);
+        const uint32_t last_group = lng ? 22u : 11u, last_keep = lng ? 24u : 16u;  // bits 110, 111 / bit 55
+        const uint32_t half_len = nbits * 6 / 5;  // rows of the power sum: signal_len = nbits * 12 / 5 samples (demod_2400.c:342)
+        uint32_t X[4] = {0, 0, 0, 0};             // the message as a 128-bit shift register, 5 bits in per group
+        uint32_t syn = 0, last_lo = 0, first_lo = 0;
+        uint64_t pw = 0;
+        uint32_t P[6] = {0, 0, 0, 0, 0, 0};       // rows 6..11 of the previous trio
+        auto take_group = [&](uint32_t u, const uint32_t (&D)[8]) {
+            uint32_t b = slice_group(D, c);
+            b = u < last_group ? b : (u == last_group ? (b & last_keep) : 0u);
+            syn ^= gs[u * 32 + b];  // the CRC is linear: crc.c:59-64,140
+            X[3] = __builtin_amdgcn_alignbit(X[3], X[2], 27);
+            X[2] = __builtin_amdgcn_alignbit(X[2], X[1], 27);
+            X[1] = __builtin_amdgcn_alignbit(X[1], X[0], 27);
+            X[0] = (X[0] << 5) | b;
+        };
+        issue(0, 0);
+        issue(1, 1);
+        for (int t2 = 0; t2 < ntrios; t2 += 2) {
 #pragma unroll
-        for (int d = 0; d < kEmitDepth; ++d) issue(d, (uint32_t)d);
-        for (uint32_t m0 = 0; m0 < count; m0 += kEmitDepth) {
+            for (int slot = 0; slot < 2; ++slot) {
+                const int t = t2 + slot;
+                uint32_t R[12];
+                rows_of(slot, t, R);
+                if (t + 2 < ntrios) issue(slot, t + 2);
+                // demod_2400.c:345-351: sum of mag^2 over rows [0, half_len) (corrected below when the frame starts in an upper half)
 #pragma unroll
-            for (int d = 0; d < kEmitDepth; ++d) {
-                const uint32_t m = m0 + d;
-                if (m >= count) break;
-                const uint32_t mi = base + m;
-                const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)l_g, (int)m), phase = (uint32_t)__builtin_amdgcn_readlane((int)l_phase, (int)m);
-                const uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)l_info, (int)m), score = (uint32_t)__builtin_amdgcn_readlane((int)l_score, (int)m);
-                const uint32_t combo = item_combo(info);
-                const bool lng = !combo_is_short(combo);
-                const uint32_t nbits = lng ? 112 : 56, ngroups = lng ? 23 : 12;
-                // the 304 magnitudes from S[g] on: win[wave][w0 + k]
-                int64_t qa;
-                const bool direct = window_of(g, qa);
-                const uint32_t w0 = direct ? (uint32_t)((int64_t)g - (int64_t)kTrailing - qa) : 0u;
-                wave_sync();
-                if (direct) {
-                    if (lane < (uint32_t)kWinChunks) {
-                        uint4 o;
-                        if constexpr (FMT == kFmtUC8) {
-                            o = uc8_chunk(raw[d][0], lut);
-                        } else if constexpr (kVecFmt) {
-                            const uint4 x0 = raw[d][0], x1 = raw[d][kRawVecs - 1];
-                            o = make_uint4(sc16_pair<FMT>(x0, 0), sc16_pair<FMT>(x0, 1), sc16_pair<FMT>(x1, 0), sc16_pair<FMT>(x1, 1));
-                        }
-                        ((uint4 *)win[wave])[lane] = o;
-                    }
-                } else {
-                    for (uint32_t k = lane; k < (uint32_t)kHalo; k += 64) win[wave][k] = (uint16_t)(stream_mag<FMT>(a, (int64_t)g + k) ^ kBias);
+                for (int k = 0; k < 12; ++k) {
+                    const uint32_t x = R[k] ^ kBias2, row = 12u * (uint32_t)t + k;
+                    const uint64_t lo = x & 0xffffu, hi = x >> 16;
+                    if (row < half_len) pw += lo * lo + hi * hi;
+                    if (row == half_len) last_lo = x & 0xffffu;
                 }
-                issue(d, m + kEmitDepth);  // this slot's registers are free again
-                wave_sync();
-                uint32_t b = 0, syn = 0;
-                if (lane < ngroups) {
-                    const RotSlicer rs(phase);
-                    b = rs.group(win[wave], (int)w0 + 19, (int)lane);
+                if (t == 0) first_lo = (R[0] ^ kBias2) & 0xffffu;
+                if (t > 0) {  // group 2t - 1: rows 12t - 6 .. 12t + 1
+                    const uint32_t D[8] = {P[0], P[1], P[2], P[3], P[4], P[5], R[0], R[1]};
+                    take_group(2u * (uint32_t)t - 1u, D);
+                }
+                {  // group 2t: rows 12t .. 12t + 7
+                    const uint32_t D[8] = {R[0], R[1], R[2], R[3], R[4], R[5], R[6], R[7]};
+                    take_group(2u * (uint32_t)t, D);
+                }
 #pragma unroll
-                    for (uint32_t j = 0; j < 5; ++j) {
-                        const uint32_t k = 5 * lane + j;
-                        if (k >= nbits) b &= ~(16u >> j);
-                        else if ((b >> (4 - j)) & 1) syn ^= sbs[k + 112 - nbits];  // crc.c:59-64, the CRC is linear
-                    }
-                }
-                if (lane < 28) grp[wave][lane] = b;
-                // demod_2400.c:345-351
-                const uint32_t signal_len = nbits * 12 / 5;
-                uint64_t pw = 0;
-                for (uint32_t k = lane; k < signal_len; k += 64) {
-                    const uint64_t mag = win[wave][w0 + 19 + k] ^ kBias;
-                    pw += mag * mag;
-                }
-                for (int off = 32; off > 0; off >>= 1) {
-                    syn ^= __shfl_xor(syn, off, 64);
-                    pw += __shfl_xor(pw, off, 64);
-                }
-                wave_sync();
-                const uint32_t df = grp[wave][0];
-                // repair: DF11 on the syndrome without its IID bits (mode_s.c:475-489), DF17/18 on all of it (:508-518)
-                uint32_t fix = 0;
-                if (combo >= kComboDf11Iid0) {
-                    const uint32_t sy = (combo <= kComboDf11IidX + 1) ? (syn & 0xffff80u) : syn;
-                    if (sy) fix = diagnose(a.tab, lng ? 1 : 0, sy);
-                    if (fix == 0xffffffffu) fix = 0;  // cannot happen for an item the scan classified; keep the frame as sliced
-                }
-                const uint32_t nerr = fix & 0xffu;
-                if (lane < 14) {
-                    uint32_t byte = 0;
-                    if (lane < nbits / 8) {
-                        const uint32_t G0 = (8 * lane) / 5, dd = 8 * lane - 5 * G0;
-                        const uint32_t v = (grp[wave][G0] << 10) | (grp[wave][G0 + 1] << 5) | grp[wave][G0 + 2];
-                        byte = (v >> (7 - dd)) & 0xffu;
-                        for (uint32_t e = 0; e < nerr; ++e) {
-                            const uint32_t p = (fix >> (8 + 8 * e)) & 0xffu;
-                            if ((p >> 3) == lane) byte ^= 1u << (7 - (p & 7));
-                        }
-                    }
-                    rec[wave][8 + lane] = (uint8_t)byte;
-                }
-                wave_sync();
-                if (lane == 0) {
-                    uint8_t *o = rec[wave];
-                    const uint64_t gg = r.g0 + g;
-                    *(uint64_t *)(o + 0) = 5 * gg + (8 + 56) * 12 + (phase + 4);  // demod_2400.c:320
-                    o[22] = (uint8_t)nbits;
-                    o[23] = (uint8_t)df;
-                    const bool parity_addr = combo <= kComboCommB;
-                    const uint32_t aa = ((uint32_t)o[9] << 16) | ((uint32_t)o[10] << 8) | o[11];
-                    *(uint32_t *)(o + 24) = syn;
-                    *(int32_t *)(o + 28) = (int32_t)nerr;
-                    *(uint32_t *)(o + 32) = parity_addr ? syn : aa;
-                    *(int32_t *)(o + 36) = (int32_t)score;
-                    *(int32_t *)(o + 40) = parity_addr ? 3 : (combo <= kComboDf11IidX + 1 ? 4 : 7);  // datasource_t
-                    *(uint32_t *)(o + 44) = (combo >= kComboDf11Iid0 && combo <= kComboDf11IidX + 1) ? (syn & 0x7fu) : 0u;
-                    const double signal_power = (double)pw / 65535.0 / 65535.0;
-                    *(double *)(o + 48) = signal_power / (double)signal_len;
-                }
-                wave_sync();
-                if (lane < 14) ((uint32_t *)&r.out[mi])[lane] = ((const uint32_t *)rec[wave])[lane];
-                ++by_errors[nerr < 3 ? nerr : 2];
+                for (int k = 0; k < 6; ++k) P[k] = R[6 + k];
             }
         }
+        // the 128-bit register has taken 2 ntrios - 1 groups; as if it had taken 24 (message bit 0 at bit 119)
+        for (int u = 2 * ntrios - 1; u < 24; ++u) {
+            X[3] = __builtin_amdgcn_alignbit(X[3], X[2], 27);
+            X[2] = __builtin_amdgcn_alignbit(X[2], X[1], 27);
+            X[1] = __builtin_amdgcn_alignbit(X[1], X[0], 27);
+            X[0] <<= 5;
+        }
+        uint32_t w[4] = {(X[3] << 8) | (X[2] >> 24), (X[2] << 8) | (X[1] >> 24), (X[1] << 8) | (X[0] >> 24), X[0] << 8};
+        const uint32_t df = w[0] >> 27;
+        if (par) pw += (uint64_t)last_lo * last_lo - (uint64_t)first_lo * first_lo;  // starts in the upper half of row 0, ends in the lower half of row half_len
+        const uint32_t signal_len = nbits * 12 / 5;
+
+        // ---- repair: DF11 on the syndrome without its IID bits (mode_s.c:475-489), DF17/18 on all of it (:508-518)
+        uint32_t fix = 0;
+        if (valid && combo >= kComboDf11Iid0) {
+            const uint32_t sy = (combo <= kComboDf11IidX + 1) ? (syn & 0xffff80u) : syn;
+            if (sy) fix = diagnose(a.tab, lng ? 1 : 0, sy);
+            if (fix == 0xffffffffu) fix = 0;  // cannot happen for an item the scan classified; keep the frame as sliced
+        }
+        const uint32_t nerr = fix & 0xffu;
+        for (uint32_t e = 0; e < nerr; ++e) {
+            const uint32_t p = (fix >> (8 + 8 * e)) & 0xffu;  // crc.c:410-418
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((p >> 5) == (uint32_t)k) w[k] ^= 1u << (31 - (p & 31));
+        }
+        if (valid) {
+            const uint64_t ts = 5 * (r.g0 + g) + (8 + 56) * 12 + (phase + 4);  // demod_2400.c:320
+            const bool parity_addr = combo <= kComboCommB;
+            const bool df11 = combo >= kComboDf11Iid0 && combo <= kComboDf11IidX + 1;
+            const double signal_power = (double)pw / 65535.0 / 65535.0;
+            const double level = signal_power / (double)signal_len;
+            uint32_t *o = (uint32_t *)&r.out[mi];  // rsb_message, packed: 14 dwords
+            o[0] = (uint32_t)ts;
+            o[1] = (uint32_t)(ts >> 32);
+            o[2] = __builtin_bswap32(w[0]);  // msg[0..3]
+            o[3] = __builtin_bswap32(w[1]);
+            o[4] = __builtin_bswap32(w[2]);
+            o[5] = (__builtin_bswap32(w[3]) & 0xffffu) | (nbits << 16) | (df << 24);  // msg[12..13], msgbits, msgtype
+            o[6] = syn;                                                             // crc
+            o[7] = nerr;                                                            // correctedbits
+            o[8] = parity_addr ? syn : (w[0] & 0xffffffu);                          // addr
+            o[9] = score;
+            o[10] = parity_addr ? 3u : (df11 ? 4u : 7u);                            // datasource_t
+            o[11] = df11 ? (syn & 0x7fu) : 0u;                                      // iid
+            const uint64_t lv = __builtin_bit_cast(uint64_t, level);
+            o[12] = (uint32_t)lv;
+            o[13] = (uint32_t)(lv >> 32);
+        }
+        by_errors[0] += (uint32_t)__popcll(__ballot(valid && nerr == 0));
+        by_errors[1] += (uint32_t)__popcll(__ballot(valid && nerr == 1));
+        by_errors[2] += (uint32_t)__popcll(__ballot(valid && nerr >= 2));
     }
     if (lane == 0)
         for (int e = 0; e < 3; ++e)
@@ -1823,7 +1867,7 @@ hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *t
                                       (int)r.n_items, s);
     if (e != hipSuccess) return e;
     return by_format(a.fmt, [&](auto F) {
-        hipLaunchKernelGGL(k_replay_emit<decltype(F)::value>, dim3(512), dim3(64 * kEmitWaves), 0, s, a, r);
+        hipLaunchKernelGGL(k_replay_emit<decltype(F)::value>, dim3(256), dim3(64 * kEmitWaves), 0, s, a, r);
         return hipGetLastError();
     });
 }
