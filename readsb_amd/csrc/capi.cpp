@@ -114,6 +114,7 @@ int setup_device(rsb_ctx *c) {
     if (!c->host_replay_only) {
         for (int w = 0; w < 2; ++w) HIP_TRY(c, hipMalloc((void **)&c->d_first_add[w], sizeof(uint32_t) << 24));
         HIP_TRY(c, hipMalloc((void **)&c->d_blk_counts, c->nblocks_cap * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_blk_start, (c->nblocks_cap + 1) * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_new_adders, rsb_ctx::kNewAddersCap * sizeof(uint2)));
         HIP_TRY(c, hipMalloc((void **)&c->d_addr_upload, 2 * IcaoFilter::kSlots * sizeof(uint32_t)));
         // the message records of the device replay reuse the candidate records' memory (one path runs per batch)
@@ -160,7 +161,9 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
     r.n_items = n_items;
     r.acc = a.sinfo[c->sorted_buf ^ 1];
     r.acc_idx = (uint32_t *)a.skeys[c->sorted_buf ^ 1];
+    r.cand = r.acc_idx + r.n_items;  // the spare key buffer holds 2 x 32 bits per item: acc_idx (written after the iterations) and cand
     r.blk_counts = c->d_blk_counts;
+    r.blk_start = c->d_blk_start;
     r.nblocks = (uint32_t)((b.pending_n + kBlock - 1) / kBlock);
     r.new_adders = c->d_new_adders;
     r.new_adders_cap = rsb_ctx::kNewAddersCap;
@@ -170,6 +173,7 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
     c->timing.replay_iterations = 0;
     std::memset(cnt + kCntChanged, 0, (kCntCount - kCntChanged) * sizeof(uint32_t));
     if (r.nblocks == 0) return 1;
+    HIP_TRY(c, launch_replay_bounds(r, s));
     bool converged = false;
     for (int it = 0; it < kMaxReplayIterations && !converged; ++it) {
         r.t_cur = c->d_first_add[c->first_cur];
@@ -248,7 +252,7 @@ void rsb_destroy(rsb_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
-                    c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_new_adders, c->d_addr_upload, c->d_means,
+                    c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_blk_start, c->d_new_adders, c->d_addr_upload, c->d_means,
                     c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state};
     for (rsb_slot &b : c->slots) {
         void *sp[] = {b.d_items, b.d_region_counts, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};

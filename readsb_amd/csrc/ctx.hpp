@@ -66,7 +66,7 @@ struct rsb_ctx {
     int first_cur = 0;
     bool filter_dirty = true;       // the tables do not mirror replay.filter() (reset, external add / expire, host replay)
     bool host_replay_only = false;  // RSB_FLAG_HOST_REPLAY
-    uint32_t *d_blk_counts = nullptr;
+    uint32_t *d_blk_counts = nullptr, *d_blk_start = nullptr;
     uint2 *d_new_adders = nullptr;
     uint32_t *d_addr_upload = nullptr;
     uint32_t out_cap = 0;

@@ -1084,10 +1084,52 @@ __device__ __forceinline__ uint32_t first_key_at_or_after(const uint64_t *keys, 
     return lo;
 }
 
-// One wavefront per 131072-sample block (one demodulate2400 call).  64 items at a time: the lane on
-// the first item of an offset picks that offset's best phase by strict '>' (demod_2400.c:290-301) and
-// asks whether decodeModesMessage would take it; the offsets that could be accepted are then chained
-// in ascending order through the greedy skip (:371), which is the only sequential part.
+// first item of every 131072-sample block in the sorted item list (blk_start[nblocks] = n_items)
+__global__ __launch_bounds__(kThreads) void k_replay_bounds(const ReplayArgs r) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i <= r.n_items; i += gridDim.x * kThreads) {
+        const int64_t prev = i == 0 ? -1 : (int64_t)min((uint64_t)r.nblocks, (r.keys[i - 1] >> 3) / kBlock);
+        const int64_t cur = i == r.n_items ? (int64_t)r.nblocks : (int64_t)min((uint64_t)r.nblocks, (r.keys[i] >> 3) / kBlock);
+        for (int64_t b = prev + 1; b <= cur; ++b) r.blk_start[b] = i;
+    }
+}
+
+// One thread per item: score it against the current first-add table; the thread on the first item of an offset picks
+// that offset's best phase by strict '>' (demod_2400.c:290-301; at most five items, one per trial phase) and asks whether
+// decodeModesMessage would take it.  cand[i] = 0, or for such an offset: (best score + 1) | best item's distance << 16 |
+// (112-bit frame) << 20.  Fully parallel: the sequential part is left to k_replay_walk.
+__global__ __launch_bounds__(kThreads) void k_replay_score(const ReplayArgs r) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads) {
+        r.acc[i] = 0;
+        const uint32_t g = (uint32_t)(r.keys[i] >> 3);
+        uint32_t out = 0;
+        if (i == 0 || (uint32_t)(r.keys[i - 1] >> 3) != g) {
+            int best = -3;
+            uint32_t best_off = 0, best_info = 0;
+            bool best_member = false;
+#pragma unroll
+            for (uint32_t d = 0; d < 5; ++d) {
+                const uint32_t e = i + d;
+                if (e >= r.n_items || (d && (uint32_t)(r.keys[e] >> 3) != g)) break;
+                const uint32_t info = r.info[e], combo = item_combo(info);
+                if (combo == kComboMarker) continue;
+                const bool member = r.t_cur[item_value(info)] <= g;  // added by a message at an earlier offset
+                const int sc = combo_score(combo, member);
+                if (sc > best) {
+                    best = sc;
+                    best_off = d;
+                    best_info = info;
+                    best_member = member;
+                }
+            }
+            if (best >= 0 && combo_decodes(item_combo(best_info), best_member))
+                out = ((uint32_t)best + 1u) | (best_off << 16) | (combo_is_short(item_combo(best_info)) ? 0u : 1u << 20);
+        }
+        r.cand[i] = out;
+    }
+}
+
+// One wavefront per 131072-sample block (one demodulate2400 call): the offsets that could be accepted, 64 items at a
+// time, are chained in ascending order through the greedy skip (demod_2400.c:371) -- the only sequential part.
 __global__ __launch_bounds__(kThreads) void k_replay_walk(const ReplayArgs r) {
     __shared__ uint32_t cand_g[kThreads / 64][64];
     __shared__ uint32_t cand_len[kThreads / 64][64];
@@ -1095,42 +1137,28 @@ __global__ __launch_bounds__(kThreads) void k_replay_walk(const ReplayArgs r) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * (kThreads / 64) + wave;
     if (b >= r.nblocks) return;  // whole wavefronts leave; no workgroup barrier below
-    const uint32_t lo = first_key_at_or_after(r.keys, r.n_items, ((uint64_t)b * kBlock) << 3);
-    const uint32_t hi = first_key_at_or_after(r.keys, r.n_items, ((uint64_t)(b + 1) * kBlock) << 3);
+    const uint32_t lo = r.blk_start[b], hi = r.blk_start[b + 1];
     uint32_t next_j = 0, accepted = 0;  // wave-uniform
+    // the next 64 items are loaded while the current ones are chained
+    uint32_t c_next = 0, g_next = 0;
+    if (lo + lane < hi) {
+        c_next = r.cand[lo + lane];
+        g_next = (uint32_t)(r.keys[lo + lane] >> 3);
+    }
     for (uint32_t base = lo; base < hi; base += 64) {
-        const uint32_t i = base + lane;
-        bool cand = false;
-        uint32_t g = 0, best_i = 0, best_info = 0;
-        int best = -2;
-        if (i < hi) {
-            const uint64_t key = r.keys[i];
-            g = (uint32_t)(key >> 3);
-            if (i == lo || (uint32_t)(r.keys[i - 1] >> 3) != g) {
-                bool best_member = false;
-                for (uint32_t e = i; e < hi; ++e) {
-                    if (e != i && (uint32_t)(r.keys[e] >> 3) != g) break;
-                    r.acc[e] = 0;
-                    const uint32_t info = r.info[e], combo = item_combo(info);
-                    if (combo == kComboMarker) continue;
-                    const bool member = r.t_cur[item_value(info)] <= g;  // added by a message at an earlier offset
-                    const int sc = combo_score(combo, member);
-                    if (sc > best) {
-                        best = sc;
-                        best_i = e;
-                        best_info = info;
-                        best_member = member;
-                    }
-                }
-                cand = best >= 0 && combo_decodes(item_combo(best_info), best_member);
-            }
+        const uint32_t i = base + lane, c = c_next, g = g_next;
+        c_next = 0;
+        if (i + 64 < hi) {
+            c_next = r.cand[i + 64];
+            g_next = (uint32_t)(r.keys[i + 64] >> 3);
         }
+        const bool cand = c != 0;
         const uint64_t cm = __ballot(cand);
         const uint32_t pos = lanes_below(cm), nc = (uint32_t)__popcll(cm);
         wave_sync();
         if (cand) {
             cand_g[wave][pos] = g;
-            cand_len[wave][pos] = combo_is_short(item_combo(best_info)) ? 134u : 268u;
+            cand_len[wave][pos] = (c >> 20) ? 268u : 134u;
         }
         wave_sync();
         for (uint32_t k = 0; k < nc; ++k) {  // every lane runs the same chain
@@ -1141,12 +1169,22 @@ __global__ __launch_bounds__(kThreads) void k_replay_walk(const ReplayArgs r) {
             accepted += take;
         }
         wave_sync();
-        if (cand && cand_ok[wave][pos]) {
-            r.acc[best_i] = (uint32_t)best + 1;
-            if (combo_adds(item_combo(best_info))) atomicMin(&r.t_next[item_value(best_info)], g + 1);
-        }
+        if (cand && cand_ok[wave][pos]) r.acc[i + ((c >> 16) & 15u)] = c & 0xffffu;
     }
     if (lane == 0) r.blk_counts[b] = accepted;
+}
+
+// The accepted messages that add their address to the filter (mode_s.c:717-726) register "first added at offset g" in the
+// next table.  One thread per item, apart from the walk: thousands of messages share an aircraft's address, and the plain
+// load in front keeps all but the first few of them from queueing on the same atomic.
+__global__ __launch_bounds__(kThreads) void k_replay_adds(const ReplayArgs r) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads) {
+        if (r.acc[i] == 0) continue;
+        const uint32_t info = r.info[i];
+        if (!combo_adds(item_combo(info))) continue;
+        const uint32_t v = item_value(info), g1 = (uint32_t)(r.keys[i] >> 3) + 1;
+        if (r.t_next[v] > g1) atomicMin(&r.t_next[v], g1);
+    }
 }
 
 // over the items that can add an address: did the table move / reset / list / fold
@@ -1843,10 +1881,17 @@ inline unsigned item_grid(uint32_t n) {
 }
 }  // namespace
 
+hipError_t launch_replay_bounds(const ReplayArgs &r, hipStream_t s) {
+    hipLaunchKernelGGL(k_replay_bounds, dim3(item_grid(r.n_items + 1)), dim3(kThreads), 0, s, r);
+    return hipGetLastError();
+}
+
 hipError_t launch_replay_iteration(const BatchArgs &a, const ReplayArgs &r, hipStream_t s) {
     hipError_t e = hipMemsetAsync(&a.counters[kCntChanged], 0, sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
+    if (r.n_items) hipLaunchKernelGGL(k_replay_score, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);
     hipLaunchKernelGGL(k_replay_walk, dim3((r.nblocks + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, s, r);
+    if (r.n_items) hipLaunchKernelGGL(k_replay_adds, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);
     if (r.n_items) hipLaunchKernelGGL(k_replay_compare, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, &a.counters[kCntChanged]);
     return hipGetLastError();
 }

@@ -97,9 +97,11 @@ struct ReplayArgs {
     const uint32_t *info;    // the items' info words, same order
     uint32_t n_items;
     uint32_t *acc;           // per item: score + 1 if this (offset, phase) is decoded and accepted, else 0
+    uint32_t *cand;          // per item: k_replay_score's verdict for the offset that starts there (scratch: shares acc_idx's buffer)
     uint32_t *acc_idx;       // indices of the accepted items, ascending
     uint32_t *t_cur;         // 2^24 x u32: 0 = in the filter before this batch, g + 1 = first added by the message at
     uint32_t *t_next;        //             offset g of this batch, 0xffffffff = never
+    uint32_t *blk_start;     // first item of every 131072-sample block, nblocks + 1 entries (launch_replay_bounds)
     uint32_t *blk_counts;    // accepted messages per 131072-sample block
     uint32_t nblocks;
     uint2 *new_adders;       // (g + 1, address) of every address learned in this batch
@@ -120,6 +122,7 @@ hipError_t launch_sort(const BatchArgs &a, uint32_t n_items, void *temp, size_t 
 hipError_t launch_unique_finalize(const BatchArgs &a, uint32_t n_items, int sorted_buf, void *temp, size_t temp_bytes, hipStream_t s);
 // device replay: one fixed-point iteration (lookup, walk, compare; counters[kCntChanged] tells whether to go on),
 // the reset of the table that becomes t_next, and the final list / fold / compact / emit step
+hipError_t launch_replay_bounds(const ReplayArgs &r, hipStream_t s);  // once per batch, before the iterations
 hipError_t launch_replay_iteration(const BatchArgs &a, const ReplayArgs &r, hipStream_t s);
 hipError_t launch_replay_reset(const BatchArgs &a, const ReplayArgs &r, uint32_t *table, hipStream_t s);
 hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s);
