@@ -157,6 +157,34 @@ int rsb_process_host(rsb_ctx *ctx, const void *iq_host, uint64_t nsamples,
  * power of each of its 131072-sample blocks.  For checking the demodulators apart from the converter's tolerance. */
 int rsb_get_batch_magnitudes(rsb_ctx *ctx, uint16_t *mag_host, uint64_t nsamples, double *block_means);
 
+/* ---- wire formats of the message list ---------------------------------------- */
+
+/* What modesQueueOutput (net_io.c:1249-1276) writes for Beast-binary clients (modesSendBeastOutput, :760-826:
+ * 0x1a, type '1'/'2'/'3', 48-bit 12 MHz timestamp, RSSI byte round(sqrt(signalLevel)*255), message; every 0x1a
+ * after the type doubled) and for raw clients (modesSendRawOutput, :859-885: "@<12 hex digits>" or "*", hex
+ * message, ";\n").  net_verbatim off: messages with two corrected bits are not forwarded (:1258,1264). */
+enum { RSB_WIRE_BEAST = 0, RSB_WIRE_RAW = 1 };
+#define RSB_WIRE_MLAT 1u       /* raw: Modes.mlat set, "@" + timestamp (net_io.c:868) */
+#define RSB_WIRE_MAX_BYTES 44u /* per message: Beast 2 + 2 * (7 + 14) (net_io.c:762); raw 14 * 2 + 15 = 43 (:861) */
+
+/* Host: records -> bytes.  *nbytes = bytes the list needs; RSB_EOVERFLOW if that exceeds cap (the first cap are stored). */
+int rsb_wire_encode(int wire, uint32_t flags, const rsb_message *msgs, size_t n, uint8_t *out, size_t cap, size_t *nbytes);
+
+/* rsb_collect with the batch delivered as that byte stream.  The records are encoded on the device (one size pass, a
+ * prefix sum, one write pass), so only the wire bytes cross PCIe (about 40 % of the records' size); batches that the
+ * host has to merge (Mode A/C) or replay are encoded on the host from the same records.  *n_msgs = messages of the
+ * batch, forwarded or not. */
+int rsb_collect_wire(rsb_ctx *ctx, int wire, uint32_t flags, uint8_t *out, size_t cap, size_t *nbytes, size_t *n_msgs);
+
+/* The forwarding rule of useModesMessage (mode_s.c:2163-2175): the first message of an address is held back; when the
+ * second arrives both go out, later ones pass.  Mode A/C messages and address 0 have no aircraft record (track.c:962-971)
+ * and pass.  Keyed on rsb_message.addr, i.e. without the non-ICAO flag the reference's DF18 field decode adds
+ * (mode_s.c:1387,1412,1425), and without the tracker's expiry (track.c:1447).  out needs room for 2n messages. */
+typedef struct rsb_forwarder rsb_forwarder;
+rsb_forwarder *rsb_forwarder_create(void);
+void rsb_forwarder_destroy(rsb_forwarder *f);
+int rsb_forwarder_push(rsb_forwarder *f, const rsb_message *in, size_t n, rsb_message *out, size_t cap, size_t *n_out);
+
 int rsb_get_stats(const rsb_ctx *ctx, rsb_stats *st);
 int rsb_get_timing(const rsb_ctx *ctx, rsb_timing *t);
 const char *rsb_last_error(const rsb_ctx *ctx);

@@ -900,3 +900,94 @@ size_t orc_ac_candidates(orc_ctx *c, const void *iq, uint64_t nsamples, orc_ac_c
     c->modeac = modeac;
     return c->nac;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * wire formats
+ * ---------------------------------------------------------------------------------------------- */
+
+#include <math.h>
+
+static size_t put_byte(uint8_t *out, size_t cap, size_t pos, uint8_t b) {
+    if (pos < cap) out[pos] = b;
+    return pos + 1;
+}
+
+static size_t put_escaped(uint8_t *out, size_t cap, size_t pos, uint8_t b) { /* net_io.c:783-786 */
+    pos = put_byte(out, cap, pos, b);
+    if (b == 0x1a) pos = put_byte(out, cap, pos, b);
+    return pos;
+}
+
+size_t orc_beast_encode(const orc_msg *m, size_t n, uint8_t *out, size_t cap) {
+    size_t pos = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (m[i].correctedbits >= 2) continue; /* net_io.c:1264 with net_verbatim off */
+        const int len = m[i].msgbits / 8;      /* net_io.c:761 */
+        char type;
+        if (len == 7) type = '2';              /* net_io.c:772-780 */
+        else if (len == 14) type = '3';
+        else if (len == 2) type = '1';
+        else continue;
+        pos = put_byte(out, cap, pos, 0x1a);
+        pos = put_byte(out, cap, pos, (uint8_t) type);
+        for (int sh = 40; sh >= 0; sh -= 8) pos = put_escaped(out, cap, pos, (uint8_t) (m[i].ts >> sh)); /* :783-806 */
+        int sig = (int) round(sqrt(m[i].signal) * 255); /* :808-812 */
+        if (m[i].signal > 0 && sig < 1) sig = 1;
+        if (sig > 255) sig = 255;
+        pos = put_escaped(out, cap, pos, (uint8_t) sig);
+        for (int j = 0; j < len; ++j) pos = put_escaped(out, cap, pos, m[i].msg[j]); /* :818-823 */
+    }
+    return pos;
+}
+
+size_t orc_raw_encode(const orc_msg *m, size_t n, int mlat, uint8_t *out, size_t cap) {
+    static const char hex[] = "0123456789ABCDEF"; /* net_io.c:849 */
+    size_t pos = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (m[i].correctedbits >= 2) continue; /* net_io.c:1258 */
+        const int len = m[i].msgbits / 8;
+        if (mlat && m[i].ts) { /* net_io.c:868-872 */
+            pos = put_byte(out, cap, pos, '@');
+            for (int sh = 44; sh >= 0; sh -= 4) pos = put_byte(out, cap, pos, (uint8_t) hex[(m[i].ts >> sh) & 15]);
+        } else {
+            pos = put_byte(out, cap, pos, '*');
+        }
+        for (int j = 0; j < len; ++j) { /* :876-879 */
+            pos = put_byte(out, cap, pos, (uint8_t) hex[m[i].msg[j] >> 4]);
+            pos = put_byte(out, cap, pos, (uint8_t) hex[m[i].msg[j] & 15]);
+        }
+        pos = put_byte(out, cap, pos, ';');
+        pos = put_byte(out, cap, pos, '\n');
+    }
+    return pos;
+}
+
+size_t orc_forward_order(const orc_msg *m, size_t n, uint32_t *idx) {
+    /* per address: number of messages so far and the index of the first one (a->messages, a->first_message) */
+    size_t cap = 64, used = 0, k = 0;
+    while (cap < 4 * n + 16) cap <<= 1;
+    uint32_t *key = calloc(cap, sizeof (uint32_t)), *cnt = calloc(cap, sizeof (uint32_t)), *first = calloc(cap, sizeof (uint32_t));
+    for (size_t i = 0; i < n; ++i) {
+        if (m[i].msgtype == 32 || m[i].addr == 0) { /* track.c:962-971: no aircraft -> mode_s.c:2164 sends unconditionally */
+            idx[k++] = (uint32_t) i;
+            continue;
+        }
+        size_t h = (m[i].addr * 2654435761u) & (cap - 1);
+        while (cnt[h] && key[h] != m[i].addr) h = (h + 1) & (cap - 1);
+        if (!cnt[h]) {
+            key[h] = m[i].addr;
+            first[h] = (uint32_t) i;
+            ++used;
+        }
+        ++cnt[h];                       /* track.c:988 */
+        if (cnt[h] > 1) {               /* mode_s.c:2167-2173 */
+            if (cnt[h] == 2) idx[k++] = first[h];
+            idx[k++] = (uint32_t) i;
+        }
+    }
+    (void) used;
+    free(key);
+    free(cnt);
+    free(first);
+    return k;
+}

@@ -97,6 +97,17 @@ typedef struct {
 } orc_ac_candidate;
 size_t orc_ac_candidates(orc_ctx *c, const void *iq, uint64_t nsamples, orc_ac_candidate *out, size_t cap);
 
+/* ---- wire formats ---- */
+/* modesSendBeastOutput (net_io.c:760-826) for each record that modesQueueOutput forwards with net_verbatim off
+ * (correctedbits < 2, :1264); returns the number of bytes (may exceed cap; only the first cap are stored) */
+size_t orc_beast_encode(const orc_msg *m, size_t n, uint8_t *out, size_t cap);
+/* modesSendRawOutput (net_io.c:859-885); mlat != 0 = Modes.mlat ("@" + 12 hex digits of the timestamp) */
+size_t orc_raw_encode(const orc_msg *m, size_t n, int mlat, uint8_t *out, size_t cap);
+/* the forwarding rule of useModesMessage (mode_s.c:2163-2175) over trackUpdateFromMessage's message count
+ * (track.c:958-988; aircraft never expire here): idx receives the indices of the records handed to
+ * modesQueueOutput, in order (a first message goes out just before the second); returns their number (<= 2n) */
+size_t orc_forward_order(const orc_msg *m, size_t n, uint32_t *idx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,12 @@ def _lib():
     lib.orc_filter_test.restype = C.c_int
     lib.orc_filter_test.argtypes = [C.c_void_p, C.c_uint32]
     lib.orc_uc8_lut.restype = C.c_void_p
+    lib.orc_beast_encode.restype = C.c_size_t
+    lib.orc_beast_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.orc_raw_encode.restype = C.c_size_t
+    lib.orc_raw_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+    lib.orc_forward_order.restype = C.c_size_t
+    lib.orc_forward_order.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     return lib
 
 
@@ -159,6 +165,30 @@ class Oracle:
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint16)), shape=(65536,)).copy()
 
 
+def beast_encode(recs: np.ndarray) -> np.ndarray:
+    """orc_beast_encode: the Beast byte stream of a message list (net_io.c:760-826)"""
+    recs = np.ascontiguousarray(recs)
+    out = np.empty(44 * recs.size + 1, dtype=np.uint8)
+    n = _lib().orc_beast_encode(recs.ctypes.data, recs.size, out.ctypes.data, out.size)
+    return out[:n].copy()
+
+
+def raw_encode(recs: np.ndarray, mlat: bool = True) -> np.ndarray:
+    """orc_raw_encode: the AVR text stream of a message list (net_io.c:859-885)"""
+    recs = np.ascontiguousarray(recs)
+    out = np.empty(43 * recs.size + 1, dtype=np.uint8)
+    n = _lib().orc_raw_encode(recs.ctypes.data, recs.size, int(mlat), out.ctypes.data, out.size)
+    return out[:n].copy()
+
+
+def forward_order(recs: np.ndarray) -> np.ndarray:
+    """orc_forward_order: indices of the records useModesMessage hands to modesQueueOutput (mode_s.c:2163-2175)"""
+    recs = np.ascontiguousarray(recs)
+    idx = np.empty(2 * recs.size + 1, dtype=np.uint32)
+    n = _lib().orc_forward_order(recs.ctypes.data, recs.size, idx.ctypes.data)
+    return idx[:n].copy()
+
+
 class RefHarness:
     """The unmodified reference, run as a child process on a temp file."""
 
@@ -205,6 +235,22 @@ class RefHarness:
             pos += 16 * n
         ka = raw[pos:pos + 8].view("<u4").copy()
         return tabs, ka
+
+    @staticmethod
+    def wire(iq: np.ndarray, fmt="UC8", nfix=1, modeac=False, forward=False):
+        """(records, beast bytes, raw bytes) as the reference's own writers (net_io.c:760-826, 859-885) produce them;
+        forward=True sends every message through the real useModesMessage (tracker + two-message rule)."""
+        with tempfile.TemporaryDirectory() as d:
+            fin, fout = os.path.join(d, "in.iq"), os.path.join(d, "out.bin")
+            iq_bytes(iq).tofile(fin)
+            subprocess.run([REF_BIN, "wire", fmt, str(int(nfix)), str(int(modeac)), str(int(forward)), fin, fout],
+                           check=True, stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+            raw = np.fromfile(fout, dtype=np.uint8)
+        nrec, nb, nr = (int(x) for x in raw[:24].view("<u8"))
+        pos = 24
+        recs = raw[pos:pos + 56 * nrec].view(REC_DTYPE).copy()
+        pos += 56 * nrec
+        return recs, raw[pos:pos + nb].copy(), raw[pos + nb:pos + nb + nr].copy()
 
     @staticmethod
     def time(path: str, fmt="UC8", nfix=1, modeac=False, dc_filter=False, reps=1) -> dict:

@@ -17,6 +17,9 @@
  *   convert <fmt> <dcfilter> <chunk> <in.iq> <out.bin>           magnitudes + per-call means
  *   crctab  <nfix> <out.bin>                                     syndrome -> errorinfo, all 2^24 syndromes folded to a digest + table dump
  *   time    <fmt> <nfix> <modeac> <dcfilter> <in.iq> <reps>      prints seconds of convert+demod (CPU baseline, kind="reference")
+ *   wire    <fmt> <nfix> <modeac> <forward> <in.iq> <out.bin>    the bytes the reference's own Beast and raw writers (net_io.c:760-826,
+ *                                                                 859-885) produce for the stream, through modesQueueOutput; forward=1 goes
+ *                                                                 through the real useModesMessage (tracker + two-message rule, mode_s.c:2163-2175)
  */
 #include "readsb.h"
 #include <inttypes.h>
@@ -46,7 +49,33 @@ static struct rec *recs;
 static size_t nrecs, caprecs;
 static int capture = 1;
 
+/* wire capture: both writers point at a service with one pretend connection and no clients; the
+ * harness drains their shared buffers after every message, so flushWrites never runs */
+static struct net_service wire_service[2];
+static uint8_t *wire_bytes[2];
+static size_t wire_len[2], wire_cap[2];
+static int wire_mode; /* 0 off, 1 modesQueueOutput per message, 2 the real useModesMessage */
+void __real_useModesMessage(struct modesMessage *mm);
+
+static void wire_drain(int k, struct net_writer *w) {
+    if (wire_len[k] + w->dataUsed > wire_cap[k]) {
+        wire_cap[k] = (wire_len[k] + w->dataUsed) * 2 + 65536;
+        wire_bytes[k] = realloc(wire_bytes[k], wire_cap[k]);
+    }
+    memcpy(wire_bytes[k] + wire_len[k], w->data, w->dataUsed);
+    wire_len[k] += w->dataUsed;
+    w->dataUsed = 0;
+}
+
 void __wrap_useModesMessage(struct modesMessage *mm) {
+    if (wire_mode) {
+        if (wire_mode == 2)
+            __real_useModesMessage(mm);
+        else
+            modesQueueOutput(mm, NULL);
+        wire_drain(0, &Modes.beast_out);
+        wire_drain(1, &Modes.raw_out);
+    }
     if (!capture)
         return;
     if (nrecs == caprecs) {
@@ -222,6 +251,37 @@ static int cmd_convert(int argc, char **argv) {
     return 0;
 }
 
+static int cmd_wire(int argc, char **argv) {
+    if (argc != 8) return 2;
+    input_format_t fmt = parse_fmt(argv[2]);
+    int nfix = atoi(argv[3]), modeac = atoi(argv[4]), forward = atoi(argv[5]);
+    size_t nbytes;
+    uint8_t *iq = slurp(argv[6], &nbytes);
+    init_modes(nfix, modeac, 0);
+    Modes.net = 1;
+    Modes.mlat = 1; /* raw output with @timestamps (net_io.c:868) */
+    Modes.net_output_flush_size = 1 << 30;
+    struct net_writer *w[2] = {&Modes.beast_out, &Modes.raw_out};
+    for (int k = 0; k < 2; ++k) {
+        wire_service[k].connections = 1;
+        wire_service[k].writer = w[k];
+        w[k]->service = &wire_service[k];
+        w[k]->data = malloc(MODES_OUT_BUF_SIZE);
+        w[k]->dataUsed = 0;
+    }
+    wire_mode = forward ? 2 : 1;
+    run_stream(fmt, iq, nbytes, modeac);
+    FILE *f = fopen(argv[7], "wb");
+    if (!f) { perror(argv[7]); return 2; }
+    uint64_t hdr[3] = {nrecs, wire_len[0], wire_len[1]};
+    fwrite(hdr, sizeof (hdr), 1, f);
+    fwrite(recs, sizeof (*recs), nrecs, f);
+    fwrite(wire_bytes[0], 1, wire_len[0], f);
+    fwrite(wire_bytes[1], 1, wire_len[1], f);
+    fclose(f);
+    return 0;
+}
+
 /* dump both syndrome tables by probing modesChecksumDiagnose over all 2^24 syndromes */
 static int cmd_crctab(int argc, char **argv) {
     if (argc != 4) return 2;
@@ -261,6 +321,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[1], "time")) rc = cmd_time(argc, argv);
         else if (!strcmp(argv[1], "convert")) rc = cmd_convert(argc, argv);
         else if (!strcmp(argv[1], "crctab")) rc = cmd_crctab(argc, argv);
+        else if (!strcmp(argv[1], "wire")) rc = cmd_wire(argc, argv);
     }
     if (rc == 2)
         fprintf(stderr, "usage: see header of oracle/ref_harness.c\n");

@@ -76,6 +76,11 @@ SYMBOLS = {
     "rsb_crc_table_size": (C.c_int, [C.c_int, C.c_int]),
     "rsb_crc_table_entry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int * 2)]),
     "rsb_uc8_lut": (_VP, []),
+    "rsb_wire_encode": (C.c_int, [C.c_int, C.c_uint32, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
+    "rsb_collect_wire": (C.c_int, [_VP, C.c_int, C.c_uint32, _VP, _SZ, C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "rsb_forwarder_create": (_VP, []),
+    "rsb_forwarder_destroy": (None, [_VP]),
+    "rsb_forwarder_push": (C.c_int, [_VP, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_host_replay": (C.c_int, [C.c_int, C.c_uint64, _VP, _SZ, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
 }
 
@@ -153,6 +158,17 @@ class Channel:
         self._check(rc, "rsb_collect")
         return out[:n.value]
 
+    def collect_wire(self, wire: str = "beast", mlat: bool = True, cap_bytes: int = 1 << 20, out: np.ndarray | None = None):
+        """rsb_collect_wire: the submitted batch as Beast / raw bytes -> (bytes, number of messages in the batch)"""
+        if out is None:
+            out = np.zeros(cap_bytes, dtype=np.uint8)
+        nb, nm = _SZ(), _SZ()
+        rc = self.l.rsb_collect_wire(self.h, WIRES[wire], WIRE_MLAT if mlat else 0, out.ctypes.data, out.size, C.byref(nb), C.byref(nm))
+        if rc == -4 and nb.value > out.size:
+            raise RsbError(f"rsb_collect_wire: {nb.value} bytes exceed cap {out.size}")
+        self._check(rc, "rsb_collect_wire")
+        return out[:nb.value], nm.value
+
     def process_host(self, iq: np.ndarray, cap: int | None = None) -> np.ndarray:
         raw = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
         ns = raw.size // self.bps
@@ -194,6 +210,48 @@ class Channel:
         t = Timing()
         self.l.rsb_get_timing(self.h, C.byref(t))
         return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+
+WIRES = {"beast": 0, "raw": 1}
+WIRE_MLAT = 1
+WIRE_MAX_BYTES = 44
+
+
+def wire_encode(msgs: np.ndarray, wire: str = "beast", mlat: bool = True) -> np.ndarray:
+    """rsb_wire_encode (host): records -> Beast / raw bytes (net_io.c:760-826, 859-885)"""
+    msgs = np.ascontiguousarray(msgs, dtype=MSG_DTYPE)
+    out = np.zeros(WIRE_MAX_BYTES * msgs.size + 1, dtype=np.uint8)
+    nb = _SZ()
+    rc = lib().rsb_wire_encode(WIRES[wire], WIRE_MLAT if mlat else 0, msgs.ctypes.data, msgs.size, out.ctypes.data, out.size, C.byref(nb))
+    if rc != 0:
+        raise RsbError(f"rsb_wire_encode rc={rc}")
+    return out[:nb.value].copy()
+
+
+class Forwarder:
+    """rsb_forwarder: the two-message rule of useModesMessage (mode_s.c:2163-2175)"""
+
+    def __init__(self):
+        self.l = lib()
+        self.h = self.l.rsb_forwarder_create()
+        if not self.h:
+            raise RsbError("rsb_forwarder_create failed")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.l.rsb_forwarder_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def push(self, msgs: np.ndarray) -> np.ndarray:
+        msgs = np.ascontiguousarray(msgs, dtype=MSG_DTYPE)
+        out = np.zeros(2 * msgs.size + 1, dtype=MSG_DTYPE)
+        n = _SZ()
+        rc = self.l.rsb_forwarder_push(self.h, msgs.ctypes.data, msgs.size, out.ctypes.data, out.size, C.byref(n))
+        if rc != 0:
+            raise RsbError(f"rsb_forwarder_push rc={rc}")
+        return out[:n.value].copy()
 
 
 def host_replay(fix_bits: int, cands: np.ndarray, ac: np.ndarray | None = None, g0: int = 0) -> np.ndarray:

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "ctx.hpp"
+#include "wire.hpp"
 
 using namespace rsb;
 
@@ -253,7 +254,7 @@ void rsb_destroy(rsb_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
                     c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_blk_start, c->d_new_adders, c->d_addr_upload, c->d_means,
-                    c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state};
+                    c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out};
     for (rsb_slot &b : c->slots) {
         void *sp[] = {b.d_items, b.d_region_counts, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
         for (void *p : sp)
@@ -377,8 +378,50 @@ int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) 
     return enqueue_batch(c, b, c->batch_args(b, iq_dev, nsamples, c->cfg.input_format), nsamples, s);
 }
 
-int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
-    if (!c || (!out && cap)) return RSB_EINVAL;
+}  // extern "C"
+
+namespace {
+
+// a batch asked for as wire bytes (rsb_collect_wire) instead of records
+struct WireRequest {
+    int wire;
+    uint32_t flags;
+    uint8_t *out;
+    size_t cap;
+    size_t nbytes;
+};
+
+// records on the device -> wire bytes on the device -> the caller's buffer
+int device_wire(rsb_ctx *c, uint32_t nmsgs, WireRequest &w, hipStream_t s) {
+    if ((size_t)nmsgs + 1 > c->wire_off_cap) {
+        if (c->d_wire_off) (void)hipFree(c->d_wire_off);
+        c->d_wire_off = nullptr;
+        c->wire_off_cap = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_wire_off, ((size_t)nmsgs + 1) * sizeof(uint32_t)));
+        c->wire_off_cap = (size_t)nmsgs + 1;
+    }
+    WireArgs a{(const rsb_message *)c->d_surv, nmsgs, w.wire, w.flags, c->d_wire_off, nullptr};
+    HIP_TRY(c, launch_wire_offsets(a, c->d_sort_temp, c->sort_temp_bytes, s));
+    uint32_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, c->d_wire_off + nmsgs, sizeof(total), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    w.nbytes = total;
+    if (total > c->wire_out_cap) {
+        if (c->d_wire_out) (void)hipFree(c->d_wire_out);
+        c->d_wire_out = nullptr;
+        c->wire_out_cap = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_wire_out, (size_t)total + total / 4));
+        c->wire_out_cap = (size_t)total + total / 4;
+    }
+    a.out = c->d_wire_out;
+    HIP_TRY(c, launch_wire_write(a, s));
+    const size_t ncopy = total < w.cap ? total : w.cap;
+    if (ncopy) HIP_TRY(c, hipMemcpyAsync(w.out, c->d_wire_out, ncopy, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return RSB_OK;
+}
+
+int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRequest *wire) {
     if (n_out) *n_out = 0;
     if (!c->any_pending()) {
         c->err = "rsb_collect: nothing submitted";
@@ -464,7 +507,13 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     rsb_stats &st = c->replay.stats();
     if (on_device) {
         const uint32_t nacc = cnt[kCntAccepted];
-        if (nac == 0) {
+        if (nac == 0 && wire) {
+            // nothing to interleave: encode where the records are, only the wire bytes cross PCIe
+            n = nacc;
+            const int rc = device_wire(c, nacc, *wire, s);
+            if (rc != RSB_OK) return rc;
+            delivered = true;
+        } else if (nac == 0) {
             // nothing to interleave: straight into the caller's buffer
             n = nacc;
             const size_t ncopy = n < cap ? n : cap;
@@ -521,6 +570,14 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     }
 
     if (n_out) *n_out = n;
+    if (wire) {
+        if (!delivered) wire->nbytes = wire_encode_host(wire->wire, wire->flags, c->msgs.data(), n, wire->out, wire->cap);
+        if (wire->nbytes > wire->cap) {
+            c->err = "rsb_collect_wire: output buffer too small";
+            return RSB_EOVERFLOW;
+        }
+        return RSB_OK;
+    }
     if (!delivered) {
         const size_t ncopy = n < cap ? n : cap;
         if (ncopy) std::memcpy(out, c->msgs.data(), ncopy * sizeof(rsb_message));
@@ -530,6 +587,24 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
         return RSB_EOVERFLOW;
     }
     return RSB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
+    if (!c || (!out && cap)) return RSB_EINVAL;
+    return collect_impl(c, out, cap, n_out, nullptr);
+}
+
+int rsb_collect_wire(rsb_ctx *c, int wire, uint32_t flags, uint8_t *out, size_t cap, size_t *nbytes, size_t *n_msgs) {
+    if (!c || (!out && cap) || !nbytes || (wire != RSB_WIRE_BEAST && wire != RSB_WIRE_RAW)) return RSB_EINVAL;
+    *nbytes = 0;
+    WireRequest w{wire, flags, out, cap, 0};
+    const int rc = collect_impl(c, nullptr, 0, n_msgs, &w);
+    *nbytes = w.nbytes;
+    return rc;
 }
 
 int rsb_process(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream, rsb_message *out, size_t cap, size_t *n_out) {

@@ -70,6 +70,9 @@ struct rsb_ctx {
     uint2 *d_new_adders = nullptr;
     uint32_t *d_addr_upload = nullptr;
     uint32_t out_cap = 0;
+    uint32_t *d_wire_off = nullptr;  // rsb_collect_wire: byte offset per message (grown on demand)
+    uint8_t *d_wire_out = nullptr;   // ... and the encoded stream
+    size_t wire_off_cap = 0, wire_out_cap = 0;
     static constexpr uint32_t kNewAddersCap = 8192;
     std::vector<uint32_t> h_blk_counts, h_addrs;
     std::vector<uint2> h_new_adders;

@@ -19,6 +19,7 @@
 // Compiled with -ffp-contract=off: every float/double product and sum below rounds on its own, as
 // in the reference's x86-64 build.
 #include "kernels.hpp"
+#include "wire.hpp"
 
 #ifndef RSB_SLICE_PREFETCH
 #define RSB_SLICE_PREFETCH 1
@@ -1075,15 +1076,6 @@ __device__ __forceinline__ bool combo_decodes(uint32_t combo, bool member) {
 __device__ __forceinline__ bool combo_is_short(uint32_t combo) { return combo == kComboApShort || (combo >= kComboDf11Iid0 && combo <= kComboDf11IidX + 1); }
 __device__ __forceinline__ bool combo_adds(uint32_t combo) { return combo == kComboDf11Iid0 || combo == kComboDf17; }  // mode_s.c:717-726
 
-__device__ __forceinline__ uint32_t first_key_at_or_after(const uint64_t *keys, uint32_t n, uint64_t key) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if (keys[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
 // first item of every 131072-sample block in the sorted item list (blk_start[nblocks] = n_items)
 __global__ __launch_bounds__(kThreads) void k_replay_bounds(const ReplayArgs r) {
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i <= r.n_items; i += gridDim.x * kThreads) {
@@ -1915,6 +1907,51 @@ hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *t
         hipLaunchKernelGGL(k_replay_emit<decltype(F)::value>, dim3(256), dim3(64 * kEmitWaves), 0, s, a, r);
         return hipGetLastError();
     });
+}
+
+// ---- wire formats: one thread per message record (wire.hpp holds the byte-level description)
+__device__ __forceinline__ rsb_message load_message(const rsb_message *p) {
+    // packed 56-byte records: 8-byte aligned, seven 64-bit loads
+    union {
+        rsb_message m;
+        uint64_t q[7];
+    } u;
+    const uint64_t *src = (const uint64_t *)p;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) u.q[k] = src[k];
+    return u.m;
+}
+
+__global__ void k_wire_sizes(const WireArgs w) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > w.n) return;
+    uint32_t len = 0;
+    if (i < w.n) wire_bytes(load_message(w.msgs + i), w.wire, w.flags, [&](uint8_t) { ++len; });
+    w.off[i] = len;  // entry n: 0, so that the exclusive sum leaves the total there
+}
+
+__global__ void k_wire_write(const WireArgs w) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n) return;
+    uint8_t *dst = w.out + w.off[i];
+    wire_bytes(load_message(w.msgs + i), w.wire, w.flags, [&](uint8_t b) { *dst++ = b; });
+}
+
+hipError_t launch_wire_offsets(const WireArgs &w, void *temp, size_t temp_bytes, hipStream_t s) {
+    size_t need = 0;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, w.off, w.off, (int)(w.n + 1), s);
+    if (e != hipSuccess) return e;
+    if (need > temp_bytes) return hipErrorOutOfMemory;
+    hipLaunchKernelGGL(k_wire_sizes, dim3((w.n + kThreads) / kThreads), dim3(kThreads), 0, s, w);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return hipcub::DeviceScan::ExclusiveSum(temp, need, w.off, w.off, (int)(w.n + 1), s);
+}
+
+hipError_t launch_wire_write(const WireArgs &w, hipStream_t s) {
+    if (w.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_wire_write, dim3((w.n + kThreads - 1) / kThreads), dim3(kThreads), 0, s, w);
+    return hipGetLastError();
 }
 
 hipError_t launch_filter_rebuild(uint32_t *t0, uint32_t *t1, const uint32_t *addrs_dev, uint32_t n, hipStream_t s) {

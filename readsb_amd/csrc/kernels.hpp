@@ -126,6 +126,18 @@ hipError_t launch_replay_bounds(const ReplayArgs &r, hipStream_t s);  // once pe
 hipError_t launch_replay_iteration(const BatchArgs &a, const ReplayArgs &r, hipStream_t s);
 hipError_t launch_replay_reset(const BatchArgs &a, const ReplayArgs &r, uint32_t *table, hipStream_t s);
 hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s);
+// wire formats (wire.hpp) of n message records on the device: launch_wire_offsets leaves the byte offset of message i in
+// off[i] and the total in off[n]; launch_wire_write stores the bytes at out + off[i]
+struct WireArgs {
+    const rsb_message *msgs;
+    uint32_t n;
+    int wire;
+    uint32_t flags;
+    uint32_t *off;  // n + 1 entries
+    uint8_t *out;
+};
+hipError_t launch_wire_offsets(const WireArgs &w, void *temp, size_t temp_bytes, hipStream_t s);
+hipError_t launch_wire_write(const WireArgs &w, hipStream_t s);
 // first-add tables := "never" everywhere, 0 for address 0 and the n given addresses
 hipError_t launch_filter_rebuild(uint32_t *t0, uint32_t *t1, const uint32_t *addrs_dev, uint32_t n, hipStream_t s);
 hipError_t launch_modeac(const BatchArgs &a, hipStream_t s);

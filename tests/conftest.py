@@ -18,4 +18,10 @@ def built():
     from oracle import oracle as orc
 
     orc._lib()
+    # torch brings its own copy of the HIP runtime: it has to see the GPU before libreadsb_amd.so (linked against
+    # /opt/rocm's) initialises it, otherwise torch reports "No HIP GPUs are available" (load order)
+    import torch
+
+    if torch.cuda.is_available():
+        torch.cuda.init()
     return True

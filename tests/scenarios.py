@@ -61,3 +61,6 @@ def convert_input(fmt, n):
     iq = rng.integers(-lim, lim, size=(n, 2), dtype=np.int64).astype("<i2")
     iq[:6] = [[1000, -2000], [lim - 1, 0], [-lim, -lim], [123, 456], [0, 0], [-1, 1]]
     return iq
+
+# scenarios whose reference Beast / raw byte streams are kept as fixtures (tests/golden/wire_*.npz)
+WIRE_SCENARIOS = ["cfg1_df11_df17", "mixed_fix1", "dense_fix2_ac", "sc16_ac"]
