@@ -76,6 +76,9 @@ def main() -> int:
     ap.add_argument("--segment", type=int, default=1 << 23, help="synthetic segment that is tiled to --samples")
     ap.add_argument("--batches", type=int, default=1, help="submit the recording as this many batches, two in flight (measured on MI355X: no gain -- the persistent "
                     "scan kernel fills every CU's LDS, so the replay kernels of the previous batch cannot run beside it -- hence 1)")
+    ap.add_argument("--output", choices=("records", "beast", "raw"), default="records",
+                    help="what a step delivers to the host: rsb_message records (default, the metric's message list) or the Beast / raw "
+                         "byte stream encoded on the device (rsb_collect_wire)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -114,6 +117,7 @@ def main() -> int:
     cap = max(1 << 16, n // 512)
     # the caller's result buffer: pinned, so the device -> host copy of the message list runs at link speed
     outbuf = torch.empty(cap * readsb_amd.MSG_DTYPE.itemsize, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE)
+    wirebuf = torch.empty(cap * readsb_amd.WIRE_MAX_BYTES if args.output != "records" else 1, dtype=torch.uint8, pin_memory=True).numpy()
     keys = ("scan_ms", "prune_ms", "sort_ms", "device_replay_ms", "copy_ms", "replay_ms", "total_ms", "replay_iterations", "replay_on_device")
     base = iq.data_ptr()
 
@@ -126,8 +130,12 @@ def main() -> int:
 
         def collect():
             nonlocal pos
-            m = ch.collect(out=outbuf[pos:])
-            pos += m.size
+            if args.output == "records":
+                m = ch.collect(out=outbuf[pos:])
+                pos += m.size
+            else:
+                b, _ = ch.collect_wire(args.output, mlat=True, out=wirebuf[pos:])
+                pos += b.size
             t = ch.timing()
             for k in keys:
                 if k == "replay_on_device":
@@ -145,7 +153,7 @@ def main() -> int:
         if tm is not None:
             for k in keys:
                 tm[k].append(acc[k])
-        return outbuf[:pos]
+        return outbuf[:pos] if args.output == "records" else wirebuf[:pos]
 
     def barrier():
         rd.barrier(dev)
@@ -161,6 +169,14 @@ def main() -> int:
     barrier()
     dt = time.perf_counter() - t0
     dt = rd.max_over_ranks(dt, dev)                      # the slowest rank's time
+    wire_check = None
+    if args.output != "records":
+        # full-size check of the device encoder: the same recording once more as records, encoded by the host encoder
+        wire_bytes = msgs.copy()
+        out_kind, args.output = args.output, "records"
+        msgs = step()
+        args.output = out_kind
+        wire_check = "ok" if np.array_equal(readsb_amd.wire_encode(msgs, out_kind, mlat=True), wire_bytes) else "WIRE-MISMATCH"
     nmsgs = sum(rd.gather_counts(int(msgs.size), dev))   # the result-count gather: the only data the ranks exchange
 
     # full-size check: the recording is `reps` copies of one segment whose length is a multiple of
@@ -204,7 +220,8 @@ def main() -> int:
                        "samples_per_gpu": n, "segment_samples": seg_n, "format": "UC8", "fix_bits": 1,
                        "batches_per_step": len(cuts) - 1, "batches_in_flight": 2 if len(cuts) > 2 else 1,
                        "channels": world, "messages_per_step": nmsgs, "survivors_per_step": st["survivors"],
-                       "full_size_check": parity},
+                       "full_size_check": parity, "output": args.output,
+                       **({"wire_bytes_per_step": int(wire_bytes.size), "wire_check": wire_check} if wire_check else {})},
             "roofline": {"bound": "hbm", "kernel": "k_scan<UC8>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": 2 * n // (len(cuts) - 1), "avg_launch_ms": scan_s * 1e3 / (len(cuts) - 1),
