@@ -65,6 +65,12 @@ typedef struct rsb_config {
  * candidate records instead of on the device.  Same results; kept as the cross-check and as the
  * path a batch falls back to when the ICAO filter is close to full (icao_filter.c:76-79). */
 #define RSB_FLAG_HOST_REPLAY 1u
+/* Exact demodulator statistics (struct stats, stats.h:61-79, as demod_2400.c:175,304-310,329-337,355-362,378-382
+ * updates them): every offset that passes the preamble gate is carried to the host replay, which then counts
+ * demod_preambles / demod_rejected_* and sums signal and noise power exactly as the reference's loop does.  Same
+ * message list; much slower (about 1 % of all offsets cross PCIe as candidate records): a statistics mode, not the
+ * fast path.  Implies RSB_FLAG_HOST_REPLAY. */
+#define RSB_FLAG_EXACT_STATS 2u
 
 /* One decoded message: the fields of struct modesMessage (readsb.h:421-439) that the hot path
  * itself produces.  Packed, 56 bytes. */
@@ -84,9 +90,12 @@ typedef struct rsb_message {
 } rsb_message;
 #pragma pack(pop)
 
-/* Counters.  The demod_* members of struct stats (stats.h:62-71) are only exact when the context
- * runs in an exact-statistics mode (not implemented yet: they stay 0); accepted[] / modeac are
- * always exact. */
+/* Counters.  demod_accepted[] / demod_modeac are always exact.  demod_preambles, demod_rejected_* and the
+ * power members below (stats.h:62-79) are the reference's only on a context created with RSB_FLAG_EXACT_STATS
+ * (they stay 0 otherwise: the fast path never sees the offsets the greedy skip hides).  One difference is kept on
+ * purpose: for a recording whose length is a multiple of 131072 the reference's reader publishes a final
+ * zero-length block (sdr_ifile.c:213-225) whose mean_power is 0/0, which turns its noise_power_sum into NaN; this
+ * library scans no such block. */
 typedef struct rsb_stats {
     uint64_t samples_processed;
     uint64_t demod_preambles, demod_rejected_bad, demod_rejected_unknown_icao;
@@ -96,6 +105,13 @@ typedef struct rsb_stats {
     uint64_t live_candidates;   /* ... with at least one phase that is not "-2 under any filter" */
     uint64_t survivors;         /* ... left after the filter-superset prune (replayed on the host) */
     uint64_t modeac_candidates;
+    /* RSB_FLAG_EXACT_STATS only (demod_2400.c:353-362, 378-382) */
+    double signal_power_sum;        /* sum over accepted messages of sum(mag^2) / 65535^2 */
+    uint64_t signal_power_count;    /* ... and of the samples summed (134 / 268 per message) */
+    double noise_power_sum;         /* per block: mean_power * length - signal power of its messages */
+    uint64_t noise_power_count;
+    double peak_signal_power;       /* largest signalLevel */
+    uint64_t strong_signal_count;   /* signalLevel > 0.50119 (-3 dBFS) */
 } rsb_stats;
 
 /* Durations of the last rsb_submit, measured with HIP events on the submit stream. */

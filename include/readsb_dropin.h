@@ -50,7 +50,9 @@ struct rsbd_converter_state; /* struct converter_state */
 typedef void (*rsbd_iq_convert_fn)(void *iq_data, uint16_t *mag_data, unsigned nsamples, struct rsbd_converter_state *state,
                                    double *out_mean_level, double *out_mean_power);
 
-/* filter_dc != 0 is not available yet: NULL + the reference's message.  The function returned takes
+/* filter_dc != 0 selects the DC-block converters (convert.c:113-162, :164-213, :374-423) as a chunked
+ * linear-recurrence scan: magnitudes within +-1 LSB of the sequential float32 IIR, state carried across
+ * calls (DESIGN.md "DC filter").  The function returned takes
  * HOST buffers, as the reference's do (it stages through device memory owned by the state).
  * out_mean_level / out_mean_power are the reference's bit for bit, also for the SC16 formats, whose
  * float32 running sums (convert.c:226-262) are taken in sample order on the device. */

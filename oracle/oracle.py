@@ -210,6 +210,19 @@ class RefHarness:
         return recs.copy(), dict(zip(STAT_NAMES, (int(x) for x in hdr[1:8])))
 
     @staticmethod
+    def stats(iq: np.ndarray, fmt="UC8", nfix=1, modeac=False, dc_filter=False) -> dict:
+        """Every demodulator member of the reference's struct stats (stats.h:61-79) after the stream; doubles bit-exact."""
+        with tempfile.TemporaryDirectory() as d:
+            fin = os.path.join(d, "in.iq")
+            iq_bytes(iq).tofile(fin)
+            out = subprocess.run([REF_BIN, "stats", fmt, str(int(nfix)), str(int(modeac)), str(int(dc_filter)), fin],
+                                 check=True, capture_output=True, text=True).stdout
+        st = json.loads(out.strip().splitlines()[-1])
+        for k in ("noise_power_sum", "signal_power_sum", "peak_signal_power"):
+            st[k] = float.fromhex(st[k])
+        return st
+
+    @staticmethod
     def convert(iq: np.ndarray, fmt="UC8", dc_filter=False, chunk=131072):
         with tempfile.TemporaryDirectory() as d:
             fin, fout = os.path.join(d, "in.iq"), os.path.join(d, "out.bin")

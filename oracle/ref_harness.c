@@ -17,6 +17,8 @@
  *   convert <fmt> <dcfilter> <chunk> <in.iq> <out.bin>           magnitudes + per-call means
  *   crctab  <nfix> <out.bin>                                     syndrome -> errorinfo, all 2^24 syndromes folded to a digest + table dump
  *   time    <fmt> <nfix> <modeac> <dcfilter> <in.iq> <reps>      prints seconds of convert+demod (CPU baseline, kind="reference")
+ *   stats   <fmt> <nfix> <modeac> <dcfilter> <in.iq>             prints every demodulator member of Modes.stats_current (stats.h:61-79) as
+ *                                                                 one JSON line, doubles as C99 hex floats (bit-exact round trip)
  *   wire    <fmt> <nfix> <modeac> <forward> <in.iq> <out.bin>    the bytes the reference's own Beast and raw writers (net_io.c:760-826,
  *                                                                 859-885) produce for the stream, through modesQueueOutput; forward=1 goes
  *                                                                 through the real useModesMessage (tracker + two-message rule, mode_s.c:2163-2175)
@@ -200,6 +202,25 @@ static int cmd_demod(int argc, char **argv) {
     return 0;
 }
 
+static int cmd_stats(int argc, char **argv) {
+    if (argc != 7) return 2;
+    input_format_t fmt = parse_fmt(argv[2]);
+    int nfix = atoi(argv[3]), modeac = atoi(argv[4]), dc = atoi(argv[5]);
+    size_t nbytes;
+    uint8_t *iq = slurp(argv[6], &nbytes);
+    capture = 0;
+    init_modes(nfix, modeac, dc);
+    run_stream(fmt, iq, nbytes, modeac);
+    const struct stats *st = &Modes.stats_current;
+    printf("{\"demod_preambles\": %u, \"demod_rejected_bad\": %u, \"demod_rejected_unknown_icao\": %u, \"demod_accepted\": [%u, %u, %u], "
+            "\"demod_modeac\": %u, \"strong_signal_count\": %u, \"noise_power_sum\": \"%a\", \"noise_power_count\": %" PRIu64 ", "
+            "\"signal_power_sum\": \"%a\", \"signal_power_count\": %" PRIu64 ", \"peak_signal_power\": \"%a\"}\n",
+            st->demod_preambles, st->demod_rejected_bad, st->demod_rejected_unknown_icao, st->demod_accepted[0], st->demod_accepted[1],
+            st->demod_accepted[2], st->demod_modeac, st->strong_signal_count, st->noise_power_sum, st->noise_power_count,
+            st->signal_power_sum, st->signal_power_count, st->peak_signal_power);
+    return 0;
+}
+
 static int cmd_time(int argc, char **argv) {
     if (argc != 8) return 2;
     input_format_t fmt = parse_fmt(argv[2]);
@@ -319,6 +340,7 @@ int main(int argc, char **argv) {
     if (argc >= 2) {
         if (!strcmp(argv[1], "demod")) rc = cmd_demod(argc, argv);
         else if (!strcmp(argv[1], "time")) rc = cmd_time(argc, argv);
+        else if (!strcmp(argv[1], "stats")) rc = cmd_stats(argc, argv);
         else if (!strcmp(argv[1], "convert")) rc = cmd_convert(argc, argv);
         else if (!strcmp(argv[1], "crctab")) rc = cmd_crctab(argc, argv);
         else if (!strcmp(argv[1], "wire")) rc = cmd_wire(argc, argv);

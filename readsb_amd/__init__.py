@@ -38,13 +38,16 @@ class Config(C.Structure):
 
 
 FLAG_HOST_REPLAY = 1
+FLAG_EXACT_STATS = 2
 
 
 class Stats(C.Structure):
     _fields_ = [("samples_processed", C.c_uint64), ("demod_preambles", C.c_uint64), ("demod_rejected_bad", C.c_uint64),
                 ("demod_rejected_unknown_icao", C.c_uint64), ("demod_accepted", C.c_uint64 * 3), ("demod_modeac", C.c_uint64),
                 ("gated_offsets", C.c_uint64), ("live_candidates", C.c_uint64), ("survivors", C.c_uint64),
-                ("modeac_candidates", C.c_uint64)]
+                ("modeac_candidates", C.c_uint64),
+                ("signal_power_sum", C.c_double), ("signal_power_count", C.c_uint64), ("noise_power_sum", C.c_double),
+                ("noise_power_count", C.c_uint64), ("peak_signal_power", C.c_double), ("strong_signal_count", C.c_uint64)]
 
 
 class Timing(C.Structure):
@@ -111,12 +114,12 @@ class Channel:
     """One receiver channel (rsb_ctx)."""
 
     def __init__(self, fmt="UC8", fix_bits=1, mode_ac=False, dc_filter=False, device=0, max_batch_samples=1 << 24, queue_div=0,
-                 host_replay=False):
+                 host_replay=False, exact_stats=False):
         self.l = lib()
         self.fmt = fmt
         self.bps = 2 if fmt == "UC8" else 4
         cfg = Config(FORMATS[fmt], int(dc_filter), int(fix_bits), int(mode_ac), int(device), int(queue_div), int(max_batch_samples),
-                     FLAG_HOST_REPLAY if host_replay else 0, 0)
+                     (FLAG_HOST_REPLAY if host_replay else 0) | (FLAG_EXACT_STATS if exact_stats else 0), 0)
         h = _VP()
         rc = self.l.rsb_create(C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -74,6 +74,8 @@ int setup_device(rsb_ctx *c) {
     c->item_cap = (uint32_t)(cap * 4 > 0x7fffffffull ? 0x7fffffffull : cap * 4);
     if (c->item_cap < 65536) c->item_cap = 65536;
     c->surv_cap = (uint32_t)(cap / 4 < 4096 ? 4096 : cap / 4);
+    c->exact_stats = (c->cfg.flags & RSB_FLAG_EXACT_STATS) != 0;
+    if (c->exact_stats) c->surv_cap = (uint32_t)cap;  // every gated offset (about 1 % of the samples on noise) becomes a candidate record
     c->ac_cap = (uint32_t)(cap / 4 < 4096 ? 4096 : cap / 4);
     c->nblocks_cap = (nmax + kBlock - 1) / kBlock + 1;
     c->scan_grid = scan_grid_size(c->cfg.device);
@@ -111,7 +113,7 @@ int setup_device(rsb_ctx *c) {
         HIP_TRY(c, hipMalloc((void **)&c->d_dc_tile_sums, c->dc_tiles_cap * sizeof(double2)));
         HIP_TRY(c, hipMalloc((void **)&c->d_dc_tile_start, c->dc_tiles_cap * sizeof(double2)));
     }
-    c->host_replay_only = (c->cfg.flags & RSB_FLAG_HOST_REPLAY) != 0;
+    c->host_replay_only = (c->cfg.flags & (RSB_FLAG_HOST_REPLAY | RSB_FLAG_EXACT_STATS)) != 0;
     if (!c->host_replay_only) {
         for (int w = 0; w < 2; ++w) HIP_TRY(c, hipMalloc((void **)&c->d_first_add[w], sizeof(uint32_t) << 24));
         HIP_TRY(c, hipMalloc((void **)&c->d_blk_counts, c->nblocks_cap * sizeof(uint32_t)));
@@ -318,7 +320,10 @@ static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t n
     HIP_TRY(c, hipEventRecord(b.ev[1], s));
     if (c->run_modes) HIP_TRY(c, launch_prune(a, s));
     HIP_TRY(c, hipEventRecord(b.ev[2], s));
-    if (c->run_ac && nsamples) {
+    b.means_on_device = nullptr;
+    if ((c->run_ac || c->exact_stats) && nsamples) {
+        // mag_buf.mean_level / mean_power of every block: demodulate2400AC's noise level (demod_2400.c:484-485) and the
+        // noise power statistic (:378-382)
         const size_t nblk = (nsamples + kBlock - 1) / kBlock;
         BatchArgs ac = a;
         if (!ac.block_means && a.fmt != kFmtUC8) {
@@ -327,7 +332,11 @@ static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t n
             ac.block_means = b.d_block_means;
         }
         if (!ac.block_means) HIP_TRY(c, hipMemsetAsync(b.d_block_sums, 0, nblk * 2 * sizeof(uint64_t), s));
-        HIP_TRY(c, launch_modeac(ac, s));
+        if (c->run_ac)
+            HIP_TRY(c, launch_modeac(ac, s));
+        else if (!ac.block_means)
+            HIP_TRY(c, launch_block_sums(ac, s));
+        b.means_on_device = ac.block_means;
     }
     if (!c->block_mode && nsamples % kBlock == 0 && nsamples) {
         // the next batch's 326-sample overlap (sdr_ifile.c:199-201)
@@ -369,10 +378,11 @@ int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) 
     hipStream_t s = (hipStream_t)stream;
     if (c->cfg.dc_filter) {
         // --dcfilter: the chunked-scan converter writes the batch's magnitudes; the scan reads those (carry = the previous batch's last 326)
+        const bool want_means = c->run_ac || c->exact_stats;
         HIP_TRY(c, launch_convert_dc(c->cfg.input_format, iq_dev, c->d_magbuf, nsamples, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state,
-                                     c->run_ac ? b.d_block_means : nullptr, s));
+                                     want_means ? b.d_block_means : nullptr, s));
         BatchArgs a = c->batch_args(b, c->d_magbuf, nsamples, kFmtMag16);
-        if (c->run_ac) a.block_means = b.d_block_means;
+        if (want_means) a.block_means = b.d_block_means;
         return enqueue_batch(c, b, a, nsamples, s);
     }
     return enqueue_batch(c, b, c->batch_args(b, iq_dev, nsamples, c->cfg.input_format), nsamples, s);
@@ -551,7 +561,23 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         c->msgs.clear();
         if (on_device)
             c->replay.merge_modeac(b.g0, c->dev_msgs, c->h_blk_counts.data(), nblocks, c->h_ac, c->msgs);
-        else
+        else if (c->exact_stats && b.pending_n) {
+            // mag_buf.mean_power of every block of the batch: from the float means, or from the integer sums (convert.c:108-110)
+            c->h_blk_mean_power.resize(nblocks);
+            if (b.means_on_device) {
+                std::vector<double> means(2 * nblocks);
+                HIP_TRY(c, hipMemcpy(means.data(), b.means_on_device, means.size() * sizeof(double), hipMemcpyDeviceToHost));
+                for (size_t k = 0; k < nblocks; ++k) c->h_blk_mean_power[k] = means[2 * k + 1];
+            } else {
+                c->h_blk_sums.resize(2 * nblocks);
+                HIP_TRY(c, hipMemcpy(c->h_blk_sums.data(), b.d_block_sums, c->h_blk_sums.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                for (size_t k = 0; k < nblocks; ++k) {
+                    const uint64_t len = std::min<uint64_t>(kBlock, b.pending_n - k * kBlock);
+                    c->h_blk_mean_power[k] = (double)c->h_blk_sums[2 * k + 1] / 65535.0 / 65535.0 / (double)(unsigned)len;
+                }
+            }
+            c->replay.run_batch(b.g0, c->h_surv, c->h_ac, c->msgs, c->h_blk_mean_power.data(), b.pending_n);
+        } else
             c->replay.run_batch(b.g0, c->h_surv, c->h_ac, c->msgs);
         n = c->msgs.size();
         if (!on_device && !c->host_replay_only) c->filter_dirty = true;  // the host moved the filter on

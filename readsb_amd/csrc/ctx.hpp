@@ -23,6 +23,7 @@ struct rsb_slot {
     double *d_block_means = nullptr;  // SC16 / SC16Q11 with Mode A/C: the float converters' per-block means
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // scan start / end, prune end, Mode A/C end
     bool pending = false;
+    const double *means_on_device = nullptr;  // per-block (mean_level, mean_power) of the pending batch, when taken from float means
     uint64_t pending_n = 0, g0 = 0;   // samples of the batch, its stream position
     hipStream_t pending_stream = nullptr;
     rsb::BatchArgs pending_args;
@@ -66,6 +67,9 @@ struct rsb_ctx {
     int first_cur = 0;
     bool filter_dirty = true;       // the tables do not mirror replay.filter() (reset, external add / expire, host replay)
     bool host_replay_only = false;  // RSB_FLAG_HOST_REPLAY
+    bool exact_stats = false;       // RSB_FLAG_EXACT_STATS: every gated offset goes to the host replay, block means are kept
+    std::vector<double> h_blk_mean_power;
+    std::vector<uint64_t> h_blk_sums;
     uint32_t *d_blk_counts = nullptr, *d_blk_start = nullptr;
     uint2 *d_new_adders = nullptr;
     uint32_t *d_addr_upload = nullptr;
@@ -153,8 +157,8 @@ struct rsb_ctx {
         a.counters = b.d_counters;
         a.block_sums = b.d_block_sums;
         a.block_means = nullptr;
-        a.emit_dead = 0;
-        a.keep_all = 0;
+        a.emit_dead = exact_stats ? 1 : 0;
+        a.keep_all = exact_stats ? 1 : 0;
         a.stage_limit = stage_limit;
         a.debug_flags = debug_flags;
         return a;

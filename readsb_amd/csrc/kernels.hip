@@ -1971,6 +1971,14 @@ hipError_t launch_block_means_float(int fmt, const void *iq, uint64_t n, uint64_
     });
 }
 
+hipError_t launch_block_sums(const BatchArgs &a, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    return by_format(a.fmt, [&](auto F) {
+        hipLaunchKernelGGL(k_block_sums<decltype(F)::value>, dim3(tiles_of(a.n)), dim3(kThreads), 0, s, a);
+        return hipGetLastError();
+    });
+}
+
 hipError_t launch_modeac(const BatchArgs &a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     return by_format(a.fmt, [&](auto F) {

@@ -141,6 +141,9 @@ hipError_t launch_wire_write(const WireArgs &w, hipStream_t s);
 // first-add tables := "never" everywhere, 0 for address 0 and the n given addresses
 hipError_t launch_filter_rebuild(uint32_t *t0, uint32_t *t1, const uint32_t *addrs_dev, uint32_t n, hipStream_t s);
 hipError_t launch_modeac(const BatchArgs &a, hipStream_t s);
+// integer formats: sum(mag), sum(mag^2) per 131072-sample block into a.block_sums (zeroed by the caller); launch_modeac
+// runs it itself when it is given no block means
+hipError_t launch_block_sums(const BatchArgs &a, hipStream_t s);
 // SC16 / SC16Q11: per block of blk_len samples the reference's float32 running sums, as means (level, power)
 hipError_t launch_block_means_float(int fmt, const void *iq, uint64_t n, uint64_t blk_len, double *means, hipStream_t s);
 // --dcfilter converters (chunked linear-recurrence scan): n samples -> n magnitudes.  tile_sums / tile_start hold one double2 per 4096

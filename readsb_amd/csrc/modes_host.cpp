@@ -400,9 +400,13 @@ static void replay_modeac_block(uint64_t g0, uint64_t blk_start, uint64_t blk_en
     }
 }
 
-void Replayer::run_batch(uint64_t g0, std::vector<Survivor> &surv, std::vector<AcCand> &ac, std::vector<rsb_message> &out) {
+void Replayer::run_batch(uint64_t g0, std::vector<Survivor> &surv, std::vector<AcCand> &ac, std::vector<rsb_message> &out,
+                         const double *blk_mean_power, uint64_t nsamples) {
     sort_by_g(surv);
     sort_by_g(ac);
+    const bool exact = blk_mean_power != nullptr;
+    std::vector<uint64_t> blk_scaled;  // exact statistics: sum_scaled_signal_power of every block (demod_2400.c:357)
+    if (exact) blk_scaled.assign(size_t((nsamples + kBlock - 1) / kBlock), 0);
     size_t is = 0, ia = 0;
     while (is < surv.size() || ia < ac.size()) {
         // the next 131072-sample block that holds anything; each block is one demodulate2400 call
@@ -417,6 +421,7 @@ void Replayer::run_batch(uint64_t g0, std::vector<Survivor> &surv, std::vector<A
             Survivor &s = surv[is];
             const uint64_t g = g0 + s.g;
             if (g < next_j) continue;  // inside the previous message (demod_2400.c:371)
+            if (exact) ++stats_.demod_preambles;  // demod_2400.c:175
             int best = -2, best_phase = -1;
             for (int p = 0; p < 5; ++p) {  // demod_2400.c:179-301, strict '>' keeps the earliest phase
                 const int sc = score_message(crc_, filter_, s.msg[p], s.vbytes[p] * 8);
@@ -425,14 +430,21 @@ void Replayer::run_batch(uint64_t g0, std::vector<Survivor> &surv, std::vector<A
                     best_phase = p;
                 }
             }
-            if (best < 0) continue;  // demod_2400.c:304-310
+            if (best < 0) {  // demod_2400.c:304-310
+                if (exact) ++(best == -1 ? stats_.demod_rejected_unknown_icao : stats_.demod_rejected_bad);
+                continue;
+            }
             rsb_message m;
             std::memset(&m, 0, sizeof(m));
             m.timestamp = 5 * g + (8 + 56) * 12 + uint64_t(best_phase + 4);  // demod_2400.c:320
             m.score = best;
             uint8_t work[14];
             std::memcpy(work, s.msg[best_phase], 14);
-            if (decode_crc_part(crc_, filter_, m, work) < 0) continue;  // demod_2400.c:329-335: no skip
+            const int result = decode_crc_part(crc_, filter_, m, work);
+            if (result < 0) {  // demod_2400.c:329-335: no skip
+                if (exact) ++(result == -1 ? stats_.demod_rejected_unknown_icao : stats_.demod_rejected_bad);
+                continue;
+            }
             std::memcpy(m.msg, work, m.msgbits / 8);
             const int signal_len = m.msgbits * 12 / 5;  // demod_2400.c:345
             const uint64_t scaled = (m.msgbits == 112) ? s.pow268 : s.pow134;
@@ -440,10 +452,23 @@ void Replayer::run_batch(uint64_t g0, std::vector<Survivor> &surv, std::vector<A
             m.signal_level = signal_power / signal_len;
             next_j = g + signal_len + 1;
             ++stats_.demod_accepted[m.correctedbits];
+            if (exact) {  // demod_2400.c:355-362
+                stats_.signal_power_sum += signal_power;
+                stats_.signal_power_count += uint64_t(signal_len);
+                blk_scaled[size_t((g - g0) / kBlock)] += scaled;
+                if (m.signal_level > stats_.peak_signal_power) stats_.peak_signal_power = m.signal_level;
+                if (m.signal_level > 0.50119) ++stats_.strong_signal_count;
+            }
             out.push_back(m);
         }
 
         replay_modeac_block(g0, blk_start, blk_end, ac, ia, stats_, out);
+    }
+    for (size_t b = 0; b < blk_scaled.size(); ++b) {  // demod_2400.c:378-382, once per demodulate2400 call
+        const uint64_t len = std::min<uint64_t>(kBlock, nsamples - b * kBlock);
+        const double sum_signal_power = blk_scaled[b] / 65535.0 / 65535.0;
+        stats_.noise_power_sum += (blk_mean_power[b] * len - sum_signal_power);
+        stats_.noise_power_count += len;
     }
 }
 

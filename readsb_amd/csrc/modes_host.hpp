@@ -141,7 +141,11 @@ public:
     const CrcTables &crc() const { return crc_; }
     rsb_stats &stats() { return stats_; }
     // g0 = stream position of the batch (multiple of kBlock); records need not be sorted.
-    void run_batch(uint64_t g0, std::vector<Survivor> &surv, std::vector<AcCand> &ac, std::vector<rsb_message> &out);
+    // Exact-statistics mode (RSB_FLAG_EXACT_STATS): surv holds EVERY gated offset of the batch, and
+    // blk_mean_power[b] = mag_buf.mean_power of block b of the nsamples-long batch; the demodulator's
+    // counters and power sums are then updated as demod_2400.c:175,304-310,329-337,355-362,378-382 do.
+    void run_batch(uint64_t g0, std::vector<Survivor> &surv, std::vector<AcCand> &ac, std::vector<rsb_message> &out,
+                   const double *blk_mean_power = nullptr, uint64_t nsamples = 0);
     // After a device replay: msgs holds the batch's Mode S messages in scan order, blk_counts[b] of them per
     // 131072-sample block; interleave each block's Mode A/C messages behind them (readsb.c:883-886).
     void merge_modeac(uint64_t g0, const std::vector<rsb_message> &msgs, const uint32_t *blk_counts, size_t nblocks,

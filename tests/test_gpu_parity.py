@@ -213,3 +213,58 @@ def test_external_add_between_batches(built):
     assert outs[0].size == outs[1].size and outs[0].tobytes() == outs[1].tobytes()
     want, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
     assert first_mismatch(want, outs[0].view(REC_DTYPE)) is None  # 0xABCDEF matches nothing in this recording
+
+
+def _full_stats():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "stats_full.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", GPU_SCENARIOS)
+def test_exact_statistics_mode(name, built):
+    """RSB_FLAG_EXACT_STATS: the demodulator's counters and power sums of struct stats (stats.h:61-79) are
+    the unmodified reference's (tests/golden/stats_full.json, made by oracle/_ref/ref_harness stats): integers equal,
+    doubles bit for bit -- and the message list does not change.  noise_power_sum is skipped where the reference's is NaN
+    (recordings that are a multiple of 131072 samples: its zero-length last block has mean_power 0/0, include/readsb_amd.h)."""
+    import math
+
+    sc, kw = SCENARIOS[name]
+    iq = generate(sc)
+    gold, gst, _ = load_demod(name)
+    ref = _full_stats()[name]
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=1 << 23, queue_div=8, exact_stats=True)
+    got = ch.process_host(iq)
+    assert first_mismatch(gold, got.view(REC_DTYPE)) is None
+    st = ch.stats()
+    ch.close()
+    for k in ("demod_preambles", "demod_rejected_bad", "demod_rejected_unknown_icao", "demod_accepted", "demod_modeac",
+              "strong_signal_count", "noise_power_count", "signal_power_count"):
+        assert st[k] == ref[k], k
+    assert st["demod_preambles"] == gst["preambles"] and st["demod_rejected_bad"] == gst["rejected_bad"]
+    for k in ("signal_power_sum", "peak_signal_power", "noise_power_sum"):
+        want = float.fromhex(ref[k])
+        if math.isnan(want):
+            assert k == "noise_power_sum" and sc.n_samples % 131072 == 0 and math.isfinite(st[k])
+        else:
+            assert st[k] == want, (k, st[k], want)
+
+
+def test_exact_statistics_across_batches(built):
+    """the same, with the recording fed in batches of two blocks: counters and sums carry across rsb_submit calls"""
+    name = "mixed_fix1"
+    sc, kw = SCENARIOS[name]
+    iq = generate(sc)
+    ref = _full_stats()[name]
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], max_batch_samples=2 * 131072, queue_div=8, exact_stats=True)
+    got = ch.process_stream_host(iq, 2)
+    gold, _, _ = load_demod(name)
+    assert first_mismatch(gold, got.view(REC_DTYPE)) is None
+    st = ch.stats()
+    ch.close()
+    for k in ("demod_preambles", "demod_rejected_bad", "demod_rejected_unknown_icao", "demod_accepted", "noise_power_count", "signal_power_count"):
+        assert st[k] == ref[k], k
+    for k in ("signal_power_sum", "peak_signal_power", "noise_power_sum"):
+        assert st[k] == float.fromhex(ref[k]), k

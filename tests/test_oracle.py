@@ -130,3 +130,23 @@ def test_oracle_matches_live_reference(seed, fmt, nfix, modeac, dc, built):
     want, wst = RefHarness.demod(iq, fmt=fmt, nfix=nfix, modeac=modeac, dc_filter=dc)
     got, gst = Oracle(fmt=fmt, nfix=nfix, modeac=modeac, dc_filter=dc).run_stream(iq)
     assert first_mismatch(want, got) is None and wst == gst
+
+
+def test_full_stats_fixture_agrees_with_message_fixtures():
+    """tests/golden/stats_full.json (reference's struct stats incl. power sums) vs the counters stored with the message lists"""
+    import json
+    import math
+
+    with open(os.path.join(GOLD, "stats_full.json")) as f:
+        full = json.load(f)
+    assert set(full) == set(SCENARIOS)
+    for name in SCENARIOS:
+        msgs, st, _ = load_demod(name)
+        ref = full[name]
+        assert [ref["demod_preambles"], ref["demod_rejected_bad"], ref["demod_rejected_unknown_icao"], *ref["demod_accepted"], ref["demod_modeac"]] == \
+            [st[k] for k in STAT_NAMES]
+        modes = msgs[msgs["msgtype"] != 32]
+        assert ref["signal_power_count"] == int((modes["msgbits"].astype(np.int64) * 12 // 5).sum())  # demod_2400.c:345,356
+        peak = float.fromhex(ref["peak_signal_power"])
+        assert peak == (float(modes["signal"].max()) if modes.size else 0.0)  # :359-360
+        assert math.isnan(float.fromhex(ref["noise_power_sum"])) == (SCENARIOS[name][0].n_samples % 131072 == 0)
