@@ -32,31 +32,37 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def make_segment(seg_samples: int, seed: int):
+def make_segment(seg_samples: int, seed: int, fmt: str = "UC8", dense: bool = False):
     from readsb_amd.synth import Scenario, generate
 
     # mixed SNR (amplitudes 0.05..0.8 FS over sigma = 2 LSB noise), DF11/DF17-dominated traffic with
     # every 7th frame carrying a 1-bit error, a few Address/Parity DFs and near-collisions
-    return generate(Scenario(seg_samples, seed=seed))
+    if not dense:
+        return generate(Scenario(seg_samples, seed=seed, fmt=fmt))
+    # BASELINE configs[4]: dense overlapping traffic at low SNR with 1- and 2-bit errors and Mode A/C replies
+    return generate(Scenario(seg_samples, seed=seed, fmt=fmt, frames_per_sec=4000, err1_every=7, err2_every=10, modeac_per_sec=300,
+                             amp_lo=0.04, amp_hi=0.54))
 
 
-def cpu_baseline(seg: np.ndarray, budget_s: float = 12.0) -> dict:
+def cpu_baseline(seg: np.ndarray, budget_s: float = 12.0, fmt: str = "UC8", nfix: int = 1, modeac: bool = False, dc: bool = False) -> dict:
     from oracle.oracle import Oracle, RefHarness
 
     n = seg.shape[0]
+    what = f"convert ({fmt}{', --dcfilter' if dc else ''}) + demodulate2400{' + demodulate2400AC' if modeac else ''}, " + \
+        {0: "--no-fix", 1: "--fix", 2: "--aggressive"}[nfix]
     if RefHarness.available():
         with tempfile.NamedTemporaryFile(suffix=".iq", delete=False) as f:
             seg.tofile(f)
             path = f.name
         try:
-            probe = RefHarness.time(path, fmt="UC8", nfix=1, reps=1)
+            probe = RefHarness.time(path, fmt=fmt, nfix=nfix, modeac=modeac, dc_filter=dc, reps=1)
             reps = max(1, int(budget_s / max(probe["seconds"], 1e-3)))
-            r = RefHarness.time(path, fmt="UC8", nfix=1, reps=reps)
+            r = RefHarness.time(path, fmt=fmt, nfix=nfix, modeac=modeac, dc_filter=dc, reps=reps)
         finally:
             os.unlink(path)
         return {"value": r["samples"] / r["seconds"] / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "reference",
-                "sample": f"{n}-sample segment of the same recording x {reps} passes (convert_uc8_nodc + demodulate2400, --fix)"}
-    o = Oracle(fmt="UC8", nfix=1)
+                "sample": f"{n}-sample segment of the same recording x {reps} passes ({what})"}
+    o = Oracle(fmt=fmt, nfix=nfix, modeac=modeac, dc_filter=dc)
     t0 = time.perf_counter()
     reps = 0
     while time.perf_counter() - t0 < budget_s:
@@ -80,6 +86,12 @@ def main() -> int:
                     help="what a step delivers to the host: rsb_message records (default, the metric's message list) or the Beast / raw "
                          "byte stream encoded on the device (rsb_collect_wire)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # the other BASELINE.json configurations (the default line stays configs[1]); parity for each is covered in tests/
+    ap.add_argument("--format", choices=("UC8", "SC16", "SC16Q11"), default="UC8", help="configs[2]: 4-byte samples (bladeRF / Pluto)")
+    ap.add_argument("--dcfilter", action="store_true", help="configs[2]: the DC-block IIR as a chunked scan")
+    ap.add_argument("--modeac", action="store_true", help="configs[4]: also demodulate2400AC")
+    ap.add_argument("--fix-bits", type=int, default=1, choices=(0, 1, 2), help="0 --no-fix, 1 --fix (default), 2 --aggressive (configs[4])")
+    ap.add_argument("--dense", action="store_true", help="configs[4] traffic: dense, low SNR, 1- and 2-bit errors, Mode A/C replies")
     args = ap.parse_args()
 
     import torch
@@ -102,9 +114,10 @@ def main() -> int:
     seg_n = min(args.segment, n)
     reps = n // seg_n
     n = reps * seg_n
-    seg = make_segment(seg_n, seed=rd.channel_seed(rank))  # every rank = its own receiver channel
+    seg = make_segment(seg_n, seed=rd.channel_seed(rank), fmt=args.format, dense=args.dense)  # every rank = its own receiver channel
+    bps = 2 if args.format == "UC8" else 4                                                   # bytes per sample
     seg_dev = torch.from_numpy(seg).to(dev)
-    iq = seg_dev.repeat(reps, 1).contiguous()  # (n, 2) uint8 = the resident recording
+    iq = seg_dev.repeat(reps, 1).contiguous()  # (n, 2) uint8 / int16 = the resident recording
     del seg_dev
     torch.cuda.synchronize()
 
@@ -112,13 +125,14 @@ def main() -> int:
     nb = max(1, args.batches)
     bs = -(-n // nb) // 131072 * 131072 or n
     cuts = list(range(0, n, bs)) + [n]
-    ch = readsb_amd.Channel(fmt="UC8", fix_bits=1, mode_ac=False, device=local_rank, max_batch_samples=max(b - a for a, b in zip(cuts, cuts[1:])), queue_div=32)
+    ch = readsb_amd.Channel(fmt=args.format, fix_bits=args.fix_bits, mode_ac=args.modeac, dc_filter=args.dcfilter, device=local_rank,
+                            max_batch_samples=max(b - a for a, b in zip(cuts, cuts[1:])), queue_div=16 if args.dense else 32)
     stream = torch.cuda.current_stream().cuda_stream
-    cap = max(1 << 16, n // 512)
+    cap = max(1 << 16, n // (256 if args.dense else 512))
     # the caller's result buffer: pinned, so the device -> host copy of the message list runs at link speed
     outbuf = torch.empty(cap * readsb_amd.MSG_DTYPE.itemsize, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE)
     wirebuf = torch.empty(cap * readsb_amd.WIRE_MAX_BYTES if args.output != "records" else 1, dtype=torch.uint8, pin_memory=True).numpy()
-    keys = ("scan_ms", "prune_ms", "sort_ms", "device_replay_ms", "copy_ms", "replay_ms", "total_ms", "replay_iterations", "replay_on_device")
+    keys = ("scan_ms", "prune_ms", "modeac_ms", "sort_ms", "device_replay_ms", "copy_ms", "replay_ms", "total_ms", "replay_iterations", "replay_on_device")
     base = iq.data_ptr()
 
     def step(tm=None):
@@ -146,7 +160,7 @@ def main() -> int:
                     acc[k] += t[k]
 
         for k in range(len(cuts) - 1):
-            ch.submit(base + 2 * cuts[k], cuts[k + 1] - cuts[k], stream)
+            ch.submit(base + bps * cuts[k], cuts[k + 1] - cuts[k], stream)
             if k >= 1:
                 collect()
         collect()
@@ -183,7 +197,7 @@ def main() -> int:
     # 131072, so from the second copy on (filter warm, real overlap) every copy must decode to the same
     # list shifted by seg_n*5 ticks; the first copies are checked against the oracle in tests/.
     parity = "n/a"
-    if reps >= 4 and seg_n % 131072 == 0:
+    if reps >= 4 and seg_n % 131072 == 0 and not args.dcfilter:  # (the DC filter's state keeps settling: its copies are not identical)
         period = seg_n * 5
         k = msgs["ts"] // period
         a, b = msgs[k == 1], msgs[k == reps - 2]  # the last copy loses the frames in its final 326 samples
@@ -193,15 +207,22 @@ def main() -> int:
         parity = "periodic-ok" if same else "PERIODICITY-MISMATCH"
 
     if rank == 0:
+        if args.format == "UC8" and args.fix_bits == 1 and not (args.modeac or args.dcfilter or args.dense):
+            workload = "configs[1]: 1 Gsample synthetic UC8 recording, mixed SNR, demodulate2400 + 1-bit CRC correction"
+        elif args.modeac or args.dense or args.fix_bits == 2:
+            workload = f"configs[4]: {args.format}, {'dense low-SNR traffic' if args.dense else 'mixed SNR'}, fix_bits {args.fix_bits}" + \
+                (", demodulate2400AC" if args.modeac else "")
+        else:
+            workload = f"configs[2]: {args.format} (4-byte samples)" + (" with the DC-block IIR as a chunked scan" if args.dcfilter else ", no DC filter")
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/hbm_traffic.py from rocprofv3 --pmc passes
         if os.path.exists(tfile):
             with open(tfile) as f:
                 t = json.load(f)
-            if t.get("samples") == n:
+            if t.get("samples") == n and args.format == "UC8" and not args.dcfilter:
                 traffic = t.get("bytes_per_launch")
         scan_s = float(np.mean(scan_ms)) / 1e3
-        achieved = 2.0 * n / scan_s / 1e9
+        achieved = float(bps) * n / scan_s / 1e9
         st = ch.stats()
         out = {
             "metric": "Msamples/s demod+CRC (UC8 @2.4MS/s)",
@@ -216,23 +237,25 @@ def main() -> int:
             "vs_baseline": None,
             "dtype": "u16",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: 1 Gsample synthetic UC8 recording, mixed SNR, demodulate2400 + 1-bit CRC correction",
-                       "samples_per_gpu": n, "segment_samples": seg_n, "format": "UC8", "fix_bits": 1,
+            "config": {"workload": workload,
+                       "samples_per_gpu": n, "segment_samples": seg_n, "format": args.format, "fix_bits": args.fix_bits,
+                       "mode_ac": bool(args.modeac), "dc_filter": bool(args.dcfilter),
                        "batches_per_step": len(cuts) - 1, "batches_in_flight": 2 if len(cuts) > 2 else 1,
                        "channels": world, "messages_per_step": nmsgs, "survivors_per_step": st["survivors"],
                        "full_size_check": parity, "output": args.output,
                        **({"wire_bytes_per_step": int(wire_bytes.size), "wire_check": wire_check} if wire_check else {})},
-            "roofline": {"bound": "hbm", "kernel": "k_scan<UC8>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": f"k_scan<{'Mag16' if args.dcfilter else args.format}>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": 2 * n // (len(cuts) - 1), "avg_launch_ms": scan_s * 1e3 / (len(cuts) - 1),
+                         "algorithmic_bytes_per_launch": bps * n // (len(cuts) - 1), "avg_launch_ms": scan_s * 1e3 / (len(cuts) - 1),
                          "note": "per k_scan launch (one batch); the launches of a step together read the whole recording once"},
-            "stage_ms": {"scan": float(np.mean(tm["scan_ms"])), "prune": float(np.mean(tm["prune_ms"])), "sort": float(np.mean(tm["sort_ms"])),
+            "stage_ms": {"scan": float(np.mean(tm["scan_ms"])), "prune": float(np.mean(tm["prune_ms"])), "modeac": float(np.mean(tm["modeac_ms"])),
+                         "sort": float(np.mean(tm["sort_ms"])),
                          "device_replay": float(np.mean(tm["device_replay_ms"])), "copy_out": float(np.mean(tm["copy_ms"])),
                          "host": float(np.mean(tm["replay_ms"])), "all_kernels": float(np.mean(tm["total_ms"])),
                          "replay_iterations": float(np.mean(tm["replay_iterations"])), "replay_on_device": int(min(tm["replay_on_device"]))},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(seg)
+            out["cpu_baseline"] = cpu_baseline(seg, fmt=args.format, nfix=args.fix_bits, modeac=args.modeac, dc=args.dcfilter)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -256,7 +256,7 @@ void rsb_destroy(rsb_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
                     c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_blk_start, c->d_new_adders, c->d_addr_upload, c->d_means,
-                    c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out};
+                    c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge};
     for (rsb_slot &b : c->slots) {
         void *sp[] = {b.d_items, b.d_region_counts, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
         for (void *p : sp)
@@ -402,7 +402,7 @@ struct WireRequest {
 };
 
 // records on the device -> wire bytes on the device -> the caller's buffer
-int device_wire(rsb_ctx *c, uint32_t nmsgs, WireRequest &w, hipStream_t s) {
+int device_wire(rsb_ctx *c, const rsb_message *msgs_dev, uint32_t nmsgs, WireRequest &w, hipStream_t s) {
     if ((size_t)nmsgs + 1 > c->wire_off_cap) {
         if (c->d_wire_off) (void)hipFree(c->d_wire_off);
         c->d_wire_off = nullptr;
@@ -410,7 +410,7 @@ int device_wire(rsb_ctx *c, uint32_t nmsgs, WireRequest &w, hipStream_t s) {
         HIP_TRY(c, hipMalloc((void **)&c->d_wire_off, ((size_t)nmsgs + 1) * sizeof(uint32_t)));
         c->wire_off_cap = (size_t)nmsgs + 1;
     }
-    WireArgs a{(const rsb_message *)c->d_surv, nmsgs, w.wire, w.flags, c->d_wire_off, nullptr};
+    WireArgs a{msgs_dev, nmsgs, w.wire, w.flags, c->d_wire_off, nullptr};
     HIP_TRY(c, launch_wire_offsets(a, c->d_sort_temp, c->sort_temp_bytes, s));
     uint32_t total = 0;
     HIP_TRY(c, hipMemcpyAsync(&total, c->d_wire_off + nmsgs, sizeof(total), hipMemcpyDeviceToHost, s));
@@ -431,6 +431,56 @@ int device_wire(rsb_ctx *c, uint32_t nmsgs, WireRequest &w, hipStream_t s) {
     return RSB_OK;
 }
 
+// After a device replay of a batch that also has Mode A/C candidates: the greedy skip of demod_2400.c:659 over the (few)
+// candidates on the host, then each block's Mode A/C messages placed behind its Mode S messages (readsb.c:883-886) by a
+// kernel, into the slot's item buffer (free once the batch is pruned).  Returns 1 and the merged list (*merged, *ntotal),
+// or 0 when that buffer is too small (the caller then merges on the host), < 0 on error.
+int device_merge_modeac(rsb_ctx *c, rsb_slot &b, uint32_t nacc, size_t nblocks, hipStream_t s, const rsb_message **merged, size_t *ntotal) {
+    if (((size_t)nacc + c->h_ac.size()) * sizeof(rsb_message) > (size_t)c->item_cap * sizeof(ItemRec)) return 0;  // before anything is counted
+    c->ac_msgs.clear();
+    c->h_ac_counts.assign(nblocks + 1, 0);
+    c->replay.modeac_messages(b.g0, nblocks, c->h_ac, c->ac_msgs, c->h_ac_counts.data());
+    const uint32_t nacm = (uint32_t)c->ac_msgs.size();
+    // one upload: blk_first[nblocks + 1], ac_before[nblocks + 1], ac_dst[nacm], then the records (8-byte aligned)
+    const size_t nwords = 2 * (nblocks + 1) + nacm, rec_off = (nwords * 4 + 7) / 8 * 8, bytes = rec_off + (size_t)nacm * sizeof(rsb_message);
+    c->h_merge.resize(bytes);
+    uint32_t *blk_first = (uint32_t *)c->h_merge.data(), *ac_before = blk_first + nblocks + 1, *ac_dst = ac_before + nblocks + 1;
+    uint32_t mfirst = 0, afirst = 0;
+    for (size_t k = 0; k < nblocks; ++k) {
+        blk_first[k] = mfirst;
+        ac_before[k] = afirst;
+        mfirst += c->h_blk_counts[k];
+        for (uint32_t t = 0; t < c->h_ac_counts[k]; ++t) ac_dst[afirst + t] = mfirst + afirst + t;  // behind the block's Mode S messages
+        afirst += c->h_ac_counts[k];
+    }
+    blk_first[nblocks] = mfirst;
+    ac_before[nblocks] = afirst;
+    if (nacm) std::memcpy(c->h_merge.data() + rec_off, c->ac_msgs.data(), (size_t)nacm * sizeof(rsb_message));
+    if (bytes > c->merge_cap) {
+        if (c->d_merge) (void)hipFree(c->d_merge);
+        c->d_merge = nullptr;
+        c->merge_cap = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_merge, bytes + bytes / 2));
+        c->merge_cap = bytes + bytes / 2;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_merge, c->h_merge.data(), bytes, hipMemcpyHostToDevice, s));
+    MergeArgs m;
+    m.modes = (const rsb_message *)c->d_surv;
+    m.n_modes = nacc;
+    m.blk_first = (const uint32_t *)c->d_merge;
+    m.ac_before = m.blk_first + nblocks + 1;
+    m.nblocks = (uint32_t)nblocks;
+    m.ac_dst = m.ac_before + nblocks + 1;
+    m.ac_msgs = (const rsb_message *)(c->d_merge + rec_off);
+    m.n_ac = nacm;
+    m.dst = (rsb_message *)b.d_items;
+    HIP_TRY(c, launch_merge_modeac(m, s));
+    HIP_TRY(c, hipStreamSynchronize(s));  // h_merge is pageable
+    *merged = m.dst;
+    *ntotal = (size_t)nacc + nacm;
+    return 1;
+}
+
 int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRequest *wire) {
     if (n_out) *n_out = 0;
     if (!c->any_pending()) {
@@ -448,6 +498,11 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     uint32_t cnt[kCntCount];
     HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->debug_flags & 256) {  // ablation runs only (RSB_ABL): survivors of the Mode A/C kernel's first two stages
+        uint32_t dbg[kCntAlloc];
+        HIP_TRY(c, hipMemcpy(dbg, b.d_counters, sizeof(dbg), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "modeac stages: F1 survivors %u, F2 survivors %u, candidates %u\n", dbg[kDbgStrips], dbg[kDbgFrames], dbg[kCntAc]);
+    }
 #ifdef RSB_STAGE_CLOCKS
     {
         uint32_t dbg[kCntAlloc];
@@ -517,17 +572,26 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     rsb_stats &st = c->replay.stats();
     if (on_device) {
         const uint32_t nacc = cnt[kCntAccepted];
-        if (nac == 0 && wire) {
-            // nothing to interleave: encode where the records are, only the wire bytes cross PCIe
-            n = nacc;
-            const int rc = device_wire(c, nacc, *wire, s);
+        const rsb_message *list = (const rsb_message *)c->d_surv;  // the batch's messages on the device
+        size_t nlist = nacc;
+        bool on_dev_list = true;
+        if (nac) {  // interleave the Mode A/C messages on the device as well
+            HIP_TRY(c, hipStreamSynchronize(s));  // h_ac
+            const int rc = device_merge_modeac(c, b, nacc, nblocks, s, &list, &nlist);
+            if (rc < 0) return rc;
+            on_dev_list = rc == 1;
+        }
+        if (on_dev_list && wire) {
+            // encode where the records are, only the wire bytes cross PCIe
+            n = nlist;
+            const int rc = device_wire(c, list, (uint32_t)nlist, *wire, s);
             if (rc != RSB_OK) return rc;
             delivered = true;
-        } else if (nac == 0) {
-            // nothing to interleave: straight into the caller's buffer
-            n = nacc;
+        } else if (on_dev_list) {
+            // straight into the caller's buffer
+            n = nlist;
             const size_t ncopy = n < cap ? n : cap;
-            if (ncopy) HIP_TRY(c, hipMemcpyAsync(out, c->d_surv, ncopy * sizeof(rsb_message), hipMemcpyDeviceToHost, s));
+            if (ncopy) HIP_TRY(c, hipMemcpyAsync(out, list, ncopy * sizeof(rsb_message), hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
             delivered = true;
         } else {

@@ -113,7 +113,11 @@ struct rsb_ctx {
     std::string err;
     std::vector<rsb::Survivor> h_surv;
     std::vector<rsb::AcCand> h_ac;
-    std::vector<rsb_message> msgs, dev_msgs;
+    std::vector<rsb_message> msgs, dev_msgs, ac_msgs;
+    std::vector<uint32_t> h_ac_counts;
+    std::vector<uint8_t> h_merge;     // device Mode A/C merge: staging of the tables and records it uploads
+    uint8_t *d_merge = nullptr;
+    size_t merge_cap = 0;
 
     rsb::BatchArgs batch_args(const rsb_slot &b, const void *iq, uint64_t n, int fmt, const void *carry = nullptr) const {
         rsb::BatchArgs a;

@@ -18,6 +18,8 @@
 //
 // Compiled with -ffp-contract=off: every float/double product and sum below rounds on its own, as
 // in the reference's x86-64 build.
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "wire.hpp"
 
@@ -476,42 +478,32 @@ __device__ __forceinline__ uint32_t sc16_pair(uint4 v, int which) {
 // Which branch of scoreModesMessage does a sliced frame take (mode_s.c:330-408)?  Works from the
 // pieces the group-parallel slicer reduces: DF + AA (the first 32 bits), the CRC syndrome, and
 // whether any message bit is set.  combo << 27 | value, or kDeadItem.
-template <bool LONG>
-__device__ uint32_t classify_fields(uint32_t w0, uint32_t syn, bool nonzero, const DeviceTables &t, uint32_t *adders, const uint32_t *bloom) {
+// One code path for 56- and 112-bit frames (lng is per lane): a wavefront that holds both kinds -- nearly every
+// one does -- then runs the Bloom test, the table lookup and the address repair once, not once per kind.
+__device__ __forceinline__ uint32_t classify_fields(bool lng, uint32_t w0, uint32_t syn, bool nonzero, const DeviceTables &t, uint32_t *adders,
+                                                     const uint32_t (*bloom)[kBloomWords]) {
     const uint32_t df = w0 >> 27, aa = w0 & 0xffffffu;
-    if (!LONG) {
-        if (!nonzero) return kDeadItem;                    // all-zero message, mode_s.c:325
-        if (df != 11) return (kComboApShort << 27) | syn;  // DF0/4/5: Address/Parity
-        const uint32_t s = syn & 0xffff80u, iid = syn & 0x7fu;
-        uint32_t info = 0;
-        if (s) {
-            const uint32_t hb = bloom_bit(s);
-            if (!((bloom[hb >> 5] >> (hb & 31)) & 1u)) return kDeadItem;  // not in the table for sure
-            info = diagnose(t, 0, s);
-            if (info == kDeadItem || (info & 0xff) > 1) return kDeadItem;  // mode_s.c:350-358
-        }
-        const uint32_t addr = repair_aa(aa, info);
-        if (iid == 0) {
-            if (s == 0) mark_adder(adders, addr);
-            return ((kComboDf11Iid0 + (info & 0xff)) << 27) | addr;
-        }
-        return ((kComboDf11IidX + (info & 0xff)) << 27) | addr;
-    } else {
-        if (df == 16 || df == 24) return (kComboApLong << 27) | syn;
-        if (df == 20 || df == 21) return (kComboCommB << 27) | syn;  // exact match or nothing (mode_s.c:391-403)
-        uint32_t info = 0;  // DF17/18
-        if (syn) {
-            const uint32_t hb = bloom_bit(syn);
-            if (!((bloom[hb >> 5] >> (hb & 31)) & 1u)) return kDeadItem;
-            info = diagnose(t, 1, syn);
-            if (info == kDeadItem) return kDeadItem;
-        }
-        const uint32_t addr = repair_aa(aa, info);
-        if (df == 17 && syn == 0) mark_adder(adders, addr);
-        const uint32_t e = info & 0xff;
-        const uint32_t sub = e ? (2 * e - 1 + (addr != aa)) : 0;
-        return (((df == 17 ? kComboDf17 : kComboDf18) + sub) << 27) | addr;
+    if (!lng && !nonzero) return kDeadItem;  // all-zero message, mode_s.c:325
+    // Address/Parity (DF0/4/5, DF16/24) and Comm-B (DF20/21: exact match or nothing, mode_s.c:391-403): the filter decides
+    const bool checked = lng ? (df == 17 || df == 18) : (df == 11);
+    if (!checked) return ((lng ? ((df == 20 || df == 21) ? kComboCommB : kComboApLong) : kComboApShort) << 27) | syn;
+    // DF11: the interrogator id rides in the low 7 syndrome bits (mode_s.c:350-358); DF17/18: the whole syndrome
+    const uint32_t s = lng ? syn : (syn & 0xffff80u), iid = lng ? 0u : (syn & 0x7fu);
+    uint32_t info = 0;
+    if (s) {
+        const uint32_t hb = bloom_bit(s);
+        if (!((bloom[lng ? 1 : 0][hb >> 5] >> (hb & 31)) & 1u)) return kDeadItem;  // not in the table for sure
+        info = diagnose(t, lng ? 1 : 0, s);
+        if (info == kDeadItem || (!lng && (info & 0xff) > 1)) return kDeadItem;
     }
+    const uint32_t addr = repair_aa(aa, info), e = info & 0xff;
+    if (s == 0 && (lng ? df == 17 : iid == 0)) mark_adder(adders, addr);  // mode_s.c:717-726
+    uint32_t combo;
+    if (lng)
+        combo = (df == 17 ? kComboDf17 : kComboDf18) + (e ? (2 * e - 1 + (addr != aa)) : 0);
+    else
+        combo = (iid == 0 ? kComboDf11Iid0 : kComboDf11IidX) + e;
+    return (combo << 27) | addr;
 }
 
 // lane i <- lane (i + 1) % 64 (DPP wave rotate; no LDS traffic)
@@ -923,12 +915,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             }
             syn = lng ? syn : syn_short;
             uint32_t cls = kDeadItem;
-            if (valid) {
-                if (lng)
-                    cls = classify_fields<true>(w0, syn, true, a.tab, a.adder_bitmap, sh.bloom[1]);
-                else
-                    cls = classify_fields<false>(w0, syn, nz != 0, a.tab, a.adder_bitmap, sh.bloom[0]);
-            }
+            if (valid) cls = classify_fields(lng, w0, syn, nz != 0, a.tab, a.adder_bitmap, sh.bloom);
             const uint64_t em = __ballot(cls != kDeadItem);
             if (cls != kDeadItem) {
                 const uint32_t pos = nitems + lanes_below(em);
@@ -1438,29 +1425,252 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
 // ------------------------------------------------------------------------------------------------
 // Mode A/C
 
-constexpr int kTile = 4096;
+// ---- Mode A/C and the block statistics it needs: one 1024-thread workgroup per 131072-sample block.
+// Pass 1 (integer formats without caller-supplied means): the block's new samples -> sum(mag), sum(mag^2) exactly as the
+// integer converters take them (convert.c:71-72,82-83,104-110).  Pass 2: the block once more (L2-resident: 256-512 KB), in
+// LDS tiles, demod_2400.c:476-622 with one thread per f1_sample.  Raw IQ comes in 16-byte loads and, for UC8, goes through
+// the folded 128 x 128 magnitude table in LDS (as in k_scan, here without the bias).
+constexpr int kAcThreads = 1024;
+constexpr int kAcTile = 32768;                           // f1 positions per LDS tile (kBlock % kAcTile == 0); 16384 (two workgroups per CU) measured slower
+constexpr int kAcQ1 = 6144, kAcQ2 = 2048;                // workgroup queues per tile: F1 survivors, F2 survivors (more run on the spot)
+constexpr int kAcChunks = (kAcTile + 74 + 7) / 8;        // 8-sample chunks per tile: 2 samples before the tile's first position, 72 after its last
+// (m[f1_sample - 1] is read behind a position; bit 19 is sliced at f1_sample + 67 and looks 2 further, demod_2400.c:587-608)
+static_assert(kBlock % kAcTile == 0 && kTrailing % 8 == 6, "tiles start 328 samples into 16-byte aligned IQ");
 
-// convert.c:71-83: per 131072-block sums over the block's NEW samples (integer converters only)
 template <int FMT>
-__global__ __launch_bounds__(kThreads) void k_block_sums(const BatchArgs a) {
-    const uint64_t base = (uint64_t)blockIdx.x * kTile;  // iq index
-    uint64_t sl = 0, sp = 0;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kTile; i += kThreads) {
-        const uint64_t idx = base + i;
-        if (idx < a.n) {
-            const uint32_t v = mag_of<FMT>(a.iq, idx, a.tab.uc8_lut);
-            sl += v;
-            sp += (uint64_t)v * v;
+__device__ __forceinline__ uint4 ac_chunk(const void *iq, int64_t chunk, const uint16_t *lut) {  // 8 samples from iq index 8 * chunk -> 8 magnitudes
+    if constexpr (FMT == kFmtUC8) {
+        return uc8_chunk(((const uint4 *)iq)[chunk], lut);
+    } else if constexpr (FMT == kFmtMag16) {
+        return ((const uint4 *)iq)[chunk];
+    } else {
+        const uint4 x0 = ((const uint4 *)iq)[2 * chunk], x1 = ((const uint4 *)iq)[2 * chunk + 1];
+        return make_uint4(sc16_pair<FMT>(x0, 0) ^ kBias2, sc16_pair<FMT>(x0, 1) ^ kBias2, sc16_pair<FMT>(x1, 0) ^ kBias2, sc16_pair<FMT>(x1, 1) ^ kBias2);
+    }
+}
+
+// the three tests both framing pulses must pass (demod_2400.c:535-546 for F1 at f1_sample, :560-573 for F2): rising edge,
+// quiet third sample, at least 6 dB over the noise
+__device__ __forceinline__ bool ac_pulse_tests(const uint16_t *m, int k, unsigned noise_level) {
+    if (!(m[k - 1] < m[k])) return false;
+    if (m[k + 2] > m[k] || m[k + 2] > m[k + 1]) return false;
+    const unsigned level = ((unsigned)m[k] + m[k + 1]) / 2;
+    return noise_level * 2 <= level;
+}
+// :551-558: F1's position on the 60 MHz clock from the power split of its two samples (float32 throughout), F2 14 bit times later
+__device__ __forceinline__ unsigned ac_f2_clock(const uint16_t *m, int j, unsigned f1_sample) {
+    const float f1a_power = (float)m[j] * (float)m[j];
+    const float f1b_power = (float)m[j + 1] * (float)m[j + 1];
+    const float fraction = f1b_power / (f1a_power + f1b_power);
+    const float clockf = 25.0f * ((float)f1_sample + fraction * fraction);
+    const unsigned f1_clock = (unsigned)((double)clockf + 0.5);
+    return f1_clock + (87 * 14);
+}
+
+struct __attribute__((aligned(16))) AcShared {
+    uint16_t lut[16384];
+    uint16_t mt[8 * kAcChunks];
+    uint16_t q1[kAcQ1], q2[kAcQ2];
+    uint64_t red[2][kAcThreads / 64];
+    uint32_t nq1, nq2;
+};
+static_assert(sizeof(AcShared) <= 160 * 1024, "LDS budget of one CU");
+
+// thresholds, the 20 bits, Gillham reordering (demod_2400.c:575-639) for a position whose F1 and F2 passed
+__device__ __forceinline__ void ac_bits(const BatchArgs &a, const uint16_t *m, uint32_t j, unsigned f1_sample, uint64_t blk_start, unsigned noise_level) {
+    const unsigned f1_level = ((unsigned)m[j] + m[j + 1]) / 2;
+    const unsigned f2_clock = ac_f2_clock(m, (int)j, f1_sample), f1_clock = f2_clock - (87 * 14);
+    const int k2 = (int)j + (int)(f2_clock / 25 - f1_sample);
+    const unsigned f2_level = ((unsigned)m[k2] + m[k2 + 1]) / 2;
+
+    const unsigned f1f2_level = f1_level > f2_level ? f1_level : f2_level;
+    const float midpoint = sqrtf((float)(noise_level * f1f2_level));
+    const unsigned signal_threshold = (unsigned)((double)midpoint * 1.41421356237309504880 + 0.5);
+    const unsigned noise_threshold = (unsigned)((double)midpoint / 1.41421356237309504880 + 0.5);
+
+    unsigned uncertain_bits = 0, noisy_bits = 0, bits = 0, clock = f1_clock;
+    for (int bit = 0; bit < 20; ++bit, clock += 87) {  // (a rolled loop: unrolled it measured 3x slower)
+        const int s = (int)j + (int)(clock / 25 - f1_sample);
+        bits <<= 1;
+        noisy_bits <<= 1;
+        uncertain_bits <<= 1;
+        if (m[s + 2] >= signal_threshold) noisy_bits |= 1;
+        if (m[s] >= signal_threshold || m[s + 1] >= signal_threshold)
+            bits |= 1;
+        else if (m[s] > noise_threshold && m[s + 1] > noise_threshold)
+            uncertain_bits |= 1;
+    }
+    if ((bits & 0x80020) != 0x80020) return;
+    if ((bits & 0x0101B) != 0) return;
+    if (noisy_bits || uncertain_bits) return;
+
+    const unsigned modeac =  // demod_2400.c:626-639
+        ((bits & 0x40000) ? 0x0010 : 0) | ((bits & 0x20000) ? 0x1000 : 0) | ((bits & 0x10000) ? 0x0020 : 0) |
+        ((bits & 0x08000) ? 0x2000 : 0) | ((bits & 0x04000) ? 0x0040 : 0) | ((bits & 0x02000) ? 0x4000 : 0) |
+        ((bits & 0x00800) ? 0x0100 : 0) | ((bits & 0x00400) ? 0x0001 : 0) | ((bits & 0x00200) ? 0x0200 : 0) |
+        ((bits & 0x00100) ? 0x0002 : 0) | ((bits & 0x00080) ? 0x0400 : 0) | ((bits & 0x00040) ? 0x0004 : 0) |
+        ((bits & 0x00004) ? 0x0080 : 0);
+
+    const uint32_t slot = atomicAdd(&a.counters[kCntAc], 1u);
+    if (slot < a.ac_cap) {
+        AcCand c;
+        c.g = (uint32_t)(blk_start + f1_sample);
+        c.f2_clock = f2_clock;
+        c.modeac = modeac;
+        a.ac[slot] = c;
+    }
+}
+
+__device__ __forceinline__ bool ac_f2_tests(const uint16_t *m, uint32_t j, unsigned f1_sample, unsigned noise_level) {  // :551-573
+    const unsigned f2_clock = ac_f2_clock(m, (int)j, f1_sample);
+    return ac_pulse_tests(m, (int)j + (int)(f2_clock / 25 - f1_sample), noise_level);
+}
+
+template <int FMT>
+__global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const int sums_only) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ac_lds[];
+    AcShared &sh = *reinterpret_cast<AcShared *>(ac_lds);
+    uint16_t *lut = sh.lut, *mt = sh.mt;
+    uint64_t (*red)[kAcThreads / 64] = sh.red;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint64_t blk = blockIdx.x, blk_start = blk * kBlock;
+    const uint32_t blk_len = (uint32_t)((a.n - blk_start < (uint64_t)kBlock) ? (a.n - blk_start) : (uint64_t)kBlock);
+    if constexpr (FMT == kFmtUC8) {
+        for (uint32_t i = tid; i < 16384; i += kAcThreads) {
+            const uint32_t ai = i & 127, aq = i >> 7;
+            lut[i ^ ((aq & 31) << 1)] = a.tab.uc8_lut[((128 + aq) << 8) | (128 + ai)];
         }
+        __syncthreads();
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        sl += __shfl_down(sl, off, 64);
-        sp += __shfl_down(sp, off, 64);
+
+    // ---- pass 1: sum(mag), sum(mag^2) over the block's new samples iq[blk_start .. blk_start + blk_len)
+    if (!a.block_means && !(a.debug_flags & 16)) {
+        uint32_t sl = 0;
+        uint64_t sp = 0;
+        auto take = [&](uint32_t v) {
+            sl += v;  // at most 128 samples per thread: no overflow
+            sp += (uint64_t)v * v;
+        };
+        uint32_t done = 0;
+        if (a.iq_aligned) {
+            const uint32_t nch = blk_len / 8;
+            for (uint32_t c = tid; c < nch; c += kAcThreads) {
+                const uint4 o = ac_chunk<FMT>(a.iq, (int64_t)(blk_start / 8 + c), lut);
+                take(o.x & 0xffffu); take(o.x >> 16); take(o.y & 0xffffu); take(o.y >> 16);
+                take(o.z & 0xffffu); take(o.z >> 16); take(o.w & 0xffffu); take(o.w >> 16);
+            }
+            done = nch * 8;
+        }
+        for (uint32_t i = done + tid; i < blk_len; i += kAcThreads) take(mag_of<FMT>(a.iq, blk_start + i, a.tab.uc8_lut));
+        uint64_t tl = sl;
+        for (int off = 32; off > 0; off >>= 1) {
+            tl += __shfl_down(tl, off, 64);
+            sp += __shfl_down(sp, off, 64);
+        }
+        if ((tid & 63) == 0) {
+            red[0][tid >> 6] = tl;
+            red[1][tid >> 6] = sp;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t x = 0, y = 0;
+            for (int w = 0; w < kAcThreads / 64; ++w) {
+                x += red[0][w];
+                y += red[1][w];
+            }
+            red[0][0] = x;
+            red[1][0] = y;
+            a.block_sums[2 * blk] = x;
+            a.block_sums[2 * blk + 1] = y;
+        }
+        __syncthreads();
     }
-    if ((threadIdx.x & 63) == 0 && (sl | sp)) {
-        const uint64_t blk = base / kBlock;
-        atomicAdd((unsigned long long *)&a.block_sums[2 * blk], (unsigned long long)sl);
-        atomicAdd((unsigned long long *)&a.block_sums[2 * blk + 1], (unsigned long long)sp);
+    if (sums_only || (a.debug_flags & 8)) return;
+
+    // convert.c:104-110 then demod_2400.c:484-485
+    const double mean_level = a.block_means ? a.block_means[2 * blk] : (double)red[0][0] / 65536.0 / (double)blk_len;
+    const double mean_power = a.block_means ? a.block_means[2 * blk + 1] : (double)red[1][0] / 65535.0 / 65535.0 / (double)blk_len;
+    const double noise_stddev = sqrt(mean_power - mean_level * mean_level);
+    const unsigned noise_level = (unsigned)((mean_power + noise_stddev) * 65535 + 0.5);
+
+    // ---- pass 2: tiles of kAcTile f1 positions; mt[i] = S[blk_start + t0 - 2 + i], i.e. m[j] = S[blk_start + t0 + j] = mt[j + 2]
+    const uint16_t *m = mt + 2;
+    for (uint32_t t0 = 0; t0 < blk_len; t0 += kAcTile) {
+        const int64_t q0 = (int64_t)(blk_start + t0) - 2 - (int64_t)kTrailing;  // iq index of mt[0]: a multiple of 8
+        if (a.iq_aligned && q0 >= 0 && q0 + 8 * kAcChunks <= (int64_t)a.n) {
+            for (uint32_t c = tid; c < (uint32_t)kAcChunks; c += kAcThreads) ((uint4 *)mt)[c] = ac_chunk<FMT>(a.iq, q0 / 8 + c, lut);
+        } else {  // the batch's first tile (carry), its last ones (end of the stream), unaligned input
+            for (uint32_t i = tid; i < 8u * kAcChunks; i += kAcThreads) mt[i] = (uint16_t)stream_mag<FMT>(a, q0 + (int64_t)kTrailing + i);
+        }
+        __syncthreads();
+        if (a.debug_flags & 32) continue;
+        // Three stages with compaction into workgroup queues in between: on noise the F1 tests pass at a few per cent of the
+        // positions and F2 at under one per cent, and a lane that goes on alone drags its whole wavefront along -- so the
+        // float steps (F2) and the 20-bit loop run on densely packed survivors of the whole tile.
+        if (tid == 0) sh.nq1 = sh.nq2 = 0;
+        __syncthreads();
+        // F1 (:535-546), four consecutive positions per lane from one 16-byte window mt[4p .. 4p + 8) = m[4p - 2 .. 4p + 6)
+        for (uint32_t p = tid; p < (uint32_t)kAcTile / 4; p += kAcThreads) {
+            const uint2 lo = ((const uint2 *)mt)[p], hi = ((const uint2 *)mt)[p + 1];
+            const uint32_t v[8] = {lo.x & 0xffffu, lo.x >> 16, lo.y & 0xffffu, lo.y >> 16, hi.x & 0xffffu, hi.x >> 16, hi.y & 0xffffu, hi.y >> 16};
+            uint32_t pass = 0;  // v[k + 2] = m[4p + k]
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned f1_sample = t0 + 4 * p + k;
+                const bool ok = f1_sample != 0 && f1_sample < blk_len  // the loop starts at 1 (:487)
+                                && v[k + 1] < v[k + 2] && v[k + 4] <= v[k + 2] && v[k + 4] <= v[k + 3] && noise_level * 2 <= (v[k + 2] + v[k + 3]) / 2;
+                pass |= (uint32_t)ok << k;
+            }
+            // slots: one reservation per wavefront, the four sub-positions one after the other
+            const uint64_t pm0 = __ballot(pass & 1u), pm1 = __ballot(pass & 2u), pm2 = __ballot(pass & 4u), pm3 = __ballot(pass & 8u);
+            const uint32_t c0 = (uint32_t)__popcll(pm0), c1 = (uint32_t)__popcll(pm1), c2 = (uint32_t)__popcll(pm2), total = c0 + c1 + c2 + (uint32_t)__popcll(pm3);
+            if (total == 0) continue;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&sh.nq1, total);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const uint32_t slots[4] = {base + lanes_below(pm0), base + c0 + lanes_below(pm1), base + c0 + c1 + lanes_below(pm2), base + c0 + c1 + c2 + lanes_below(pm3)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!((pass >> k) & 1u)) continue;
+                const uint32_t j = 4 * p + k;
+                if (slots[k] < (uint32_t)kAcQ1)
+                    sh.q1[slots[k]] = (uint16_t)j;
+                else if (ac_f2_tests(m, j, t0 + j, noise_level))  // queue full: on the spot
+                    ac_bits(a, m, j, t0 + j, blk_start, noise_level);
+            }
+        }
+        __syncthreads();
+        if (a.debug_flags & 64) continue;
+        const uint32_t nq1 = min(sh.nq1, (uint32_t)kAcQ1);
+        for (uint32_t cb = (tid & ~63u); cb < nq1; cb += kAcThreads) {  // F2 (:551-573)
+            const uint32_t ci = cb + lane;
+            uint32_t j = 0;
+            bool pass = false;
+            if (ci < nq1) {
+                j = sh.q1[ci];
+                pass = ac_f2_tests(m, j, t0 + j, noise_level);
+            }
+            const uint64_t pm = __ballot(pass);
+            if (pm == 0) continue;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&sh.nq2, (uint32_t)__popcll(pm));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (pass) {
+                const uint32_t slot = base + lanes_below(pm);
+                if (slot < (uint32_t)kAcQ2)
+                    sh.q2[slot] = (uint16_t)j;
+                else
+                    ac_bits(a, m, j, t0 + j, blk_start, noise_level);
+            }
+        }
+        __syncthreads();
+        if (a.debug_flags & 128) continue;
+        const uint32_t nq2 = min(sh.nq2, (uint32_t)kAcQ2);
+        for (uint32_t ci = tid; ci < nq2; ci += kAcThreads) {  // thresholds and the 20 bits (:575-639)
+            const uint32_t j = sh.q2[ci];
+            ac_bits(a, m, j, t0 + j, blk_start, noise_level);
+        }
+        __syncthreads();
     }
 }
 
@@ -1504,93 +1714,6 @@ __global__ __launch_bounds__(64) void k_block_means_float(const void *iq, uint64
     }
 }
 
-constexpr int kAcBack = 1;    // m[f1_sample - 1]
-constexpr int kAcAhead = 72;  // bit 19 is sliced at f1_sample + 67 and looks 2 further (demod_2400.c:587-608)
-
-// demod_2400.c:476-622 with one thread per f1_sample; the greedy skip (:659) is applied on the host.
-template <int FMT>
-__global__ __launch_bounds__(kThreads) void k_modeac(const BatchArgs a) {
-    __shared__ uint16_t mt[kAcBack + kTile + kAcAhead];
-    const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
-    const uint16_t *m = mt + kAcBack;  // m[i] = S[t0 + i]
-    for (uint32_t i = threadIdx.x; i < kAcBack + kTile + kAcAhead; i += kThreads)
-        mt[i] = (uint16_t)stream_mag<FMT>(a, (int64_t)(t0 + i) - kAcBack);
-    __syncthreads();
-
-    // the tile lies inside one block (kBlock % kTile == 0)
-    const uint64_t blk = t0 / kBlock;
-    const uint64_t blk_start = blk * kBlock;
-    const uint64_t blk_len = (a.n - blk_start < (uint64_t)kBlock) ? (a.n - blk_start) : (uint64_t)kBlock;
-    // convert.c:104-110 then demod_2400.c:484-485
-    const double mean_level = a.block_means ? a.block_means[2 * blk] : (double)a.block_sums[2 * blk] / 65536.0 / (double)(unsigned)blk_len;
-    const double mean_power = a.block_means ? a.block_means[2 * blk + 1] : (double)a.block_sums[2 * blk + 1] / 65535.0 / 65535.0 / (double)(unsigned)blk_len;
-    const double noise_stddev = sqrt(mean_power - mean_level * mean_level);
-    const unsigned noise_level = (unsigned)((mean_power + noise_stddev) * 65535 + 0.5);
-
-    for (uint32_t j = threadIdx.x; j < (uint32_t)kTile; j += kThreads) {
-        const uint64_t g = t0 + j;
-        if (g >= a.n) break;
-        const unsigned f1_sample = (unsigned)(g - blk_start);
-        if (f1_sample == 0) continue;  // the loop starts at 1 (demod_2400.c:487)
-
-        if (!(m[j - 1] < m[j])) continue;
-        if (m[j + 2] > m[j] || m[j + 2] > m[j + 1]) continue;
-        const unsigned f1_level = ((unsigned)m[j] + m[j + 1]) / 2;
-        if (noise_level * 2 > f1_level) continue;
-
-        const float f1a_power = (float)m[j] * (float)m[j];
-        const float f1b_power = (float)m[j + 1] * (float)m[j + 1];
-        const float fraction = f1b_power / (f1a_power + f1b_power);
-        const float clockf = 25.0f * ((float)f1_sample + fraction * fraction);
-        const unsigned f1_clock = (unsigned)((double)clockf + 0.5);
-
-        const unsigned f2_clock = f1_clock + (87 * 14);
-        const unsigned f2_sample = f2_clock / 25;
-        const int k2 = (int)j + (int)(f2_sample - f1_sample);
-        if (!(m[k2 - 1] < m[k2])) continue;
-        if (m[k2 + 2] > m[k2] || m[k2 + 2] > m[k2 + 1]) continue;
-        const unsigned f2_level = ((unsigned)m[k2] + m[k2 + 1]) / 2;
-        if (noise_level * 2 > f2_level) continue;
-
-        const unsigned f1f2_level = f1_level > f2_level ? f1_level : f2_level;
-        const float midpoint = sqrtf((float)(noise_level * f1f2_level));
-        const unsigned signal_threshold = (unsigned)((double)midpoint * 1.41421356237309504880 + 0.5);
-        const unsigned noise_threshold = (unsigned)((double)midpoint / 1.41421356237309504880 + 0.5);
-
-        unsigned uncertain_bits = 0, noisy_bits = 0, bits = 0, clock = f1_clock;
-        for (int bit = 0; bit < 20; ++bit, clock += 87) {
-            const int s = (int)j + (int)(clock / 25 - f1_sample);
-            bits <<= 1;
-            noisy_bits <<= 1;
-            uncertain_bits <<= 1;
-            if (m[s + 2] >= signal_threshold) noisy_bits |= 1;
-            if (m[s] >= signal_threshold || m[s + 1] >= signal_threshold)
-                bits |= 1;
-            else if (m[s] > noise_threshold && m[s + 1] > noise_threshold)
-                uncertain_bits |= 1;
-        }
-        if ((bits & 0x80020) != 0x80020) continue;
-        if ((bits & 0x0101B) != 0) continue;
-        if (noisy_bits || uncertain_bits) continue;
-
-        const unsigned modeac =  // demod_2400.c:626-639
-            ((bits & 0x40000) ? 0x0010 : 0) | ((bits & 0x20000) ? 0x1000 : 0) | ((bits & 0x10000) ? 0x0020 : 0) |
-            ((bits & 0x08000) ? 0x2000 : 0) | ((bits & 0x04000) ? 0x0040 : 0) | ((bits & 0x02000) ? 0x4000 : 0) |
-            ((bits & 0x00800) ? 0x0100 : 0) | ((bits & 0x00400) ? 0x0001 : 0) | ((bits & 0x00200) ? 0x0200 : 0) |
-            ((bits & 0x00100) ? 0x0002 : 0) | ((bits & 0x00080) ? 0x0400 : 0) | ((bits & 0x00040) ? 0x0004 : 0) |
-            ((bits & 0x00004) ? 0x0080 : 0);
-
-        const uint32_t slot = atomicAdd(&a.counters[kCntAc], 1u);
-        if (slot < a.ac_cap) {
-            AcCand c;
-            c.g = (uint32_t)g;
-            c.f2_clock = f2_clock;
-            c.modeac = modeac;
-            a.ac[slot] = c;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // stand-alone converter: magnitudes to HBM (+ exact integer sums when asked)
 
@@ -1627,22 +1750,13 @@ __global__ __launch_bounds__(kThreads) void k_convert(const void *iq, uint16_t *
 
 constexpr int kDcPerThread = 16, kDcTile = kThreads * kDcPerThread;  // 4096 samples; kBlock % kDcTile == 0
 
-template <int FMT>
-__device__ __forceinline__ void dc_sample(const void *iq, uint64_t i, float &fI, float &fQ) {
-    if constexpr (FMT == kFmtUC8) {
-        const uchar2 v = ((const uchar2 *)iq)[i];
-        fI = ((float)v.x - 127.5f) / 127.5f;  // convert.c:131-132
-        fQ = ((float)v.y - 127.5f) / 127.5f;
-    } else {
-        const short2 v = ((const short2 *)iq)[i];
-        constexpr float scale = (FMT == kFmtSC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);  // exact: a power of two
-        fI = (float)v.x * scale;
-        fQ = (float)v.y * scale;
-    }
-}
-
-// inclusive scan over the workgroup's threads of the per-thread contributions: v[t] = sum_{u <= t} m^(t-u) * own[u], m = dc_b^16
-__device__ __forceinline__ double2 dc_block_scan(double2 own, double m, double2 *sh) {
+// scan over the workgroup's threads of the per-thread contributions: incl[t] = sum_{u <= t} m^(t-u) * own[u] (m = dc_b^16), and
+// excl[t] = incl[t - 1] (0 for t = 0).  Through LDS with barriers: a shuffle-based scan (64-bit __shfl_up = two ds_bpermute
+// each) measured three times slower than this on MI355X.
+struct DcScan {
+    double2 incl, excl;
+};
+__device__ __forceinline__ DcScan dc_block_scan(double2 own, double m, double2 *sh) {
     const uint32_t t = threadIdx.x;
     sh[t] = own;
     __syncthreads();
@@ -1659,25 +1773,82 @@ __device__ __forceinline__ double2 dc_block_scan(double2 own, double m, double2 
         __syncthreads();
         w *= w;
     }
-    return own;
+    DcScan r;
+    r.incl = own;
+    r.excl = t ? sh[t - 1] : make_double2(0, 0);
+    return r;
 }
+
+__device__ __forceinline__ void dc_uc8_table(float *uc8f) {  // before the first __syncthreads of the kernel
+    for (uint32_t v = threadIdx.x; v < 256; v += kThreads) uc8f[v] = ((float)v - 127.5f) / 127.5f;
+}
+
+// A thread keeps its 16 samples as the raw words it loaded and decodes them in both loops: holding them as 32 floats, with the
+// 16 square roots scheduled side by side, took 248 VGPRs (one wavefront per SIMD).
+template <int FMT>
+struct DcRaw {
+    static constexpr int kWords = (FMT == kFmtUC8) ? kDcPerThread / 2 : kDcPerThread;
+    uint32_t w[kWords];
+    __device__ __forceinline__ void load(const void *iq, uint64_t first, uint64_t n, bool aligned) {
+        constexpr int bps = (FMT == kFmtUC8) ? 2 : 4;
+        if (aligned && first + kDcPerThread <= n) {
+            const uint4 *p = (const uint4 *)((const uint8_t *)iq + bps * first);
+#pragma unroll
+            for (int v = 0; v < kWords / 4; ++v) {
+                const uint4 x = p[v];
+                w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w;
+            }
+        } else {  // the recording's last tile, unaligned input: sample by sample (what lies beyond n is never used)
+#pragma unroll
+            for (int k = 0; k < kWords; ++k) w[k] = 0;
+#pragma unroll
+            for (int k = 0; k < kDcPerThread; ++k) {
+                if (first + k >= n) continue;
+                if constexpr (FMT == kFmtUC8)
+                    w[k >> 1] |= (uint32_t)((const uint16_t *)iq)[first + k] << (16 * (k & 1));
+                else
+                    w[k] = ((const uint32_t *)iq)[first + k];
+            }
+        }
+    }
+    // uc8f: the 256 values ((float)v - 127.5f) / 127.5f of convert.c:131-132 in LDS (dc_uc8_table): a float division costs more than a lookup
+    __device__ __forceinline__ void sample(int k, const float *uc8f, float &fI, float &fQ) const {
+        if constexpr (FMT == kFmtUC8) {
+            const uint32_t x = w[k >> 1] >> (16 * (k & 1));
+            fI = uc8f[x & 0xffu];
+            fQ = uc8f[(x >> 8) & 0xffu];
+        } else {
+            constexpr float scale = (FMT == kFmtSC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);  // exact: a power of two
+            fI = (float)(short)(w[k] & 0xffffu) * scale;
+            fQ = (float)(short)(w[k] >> 16) * scale;
+        }
+    }
+};
 
 // phase 1: the state each tile would end in when started from zero
 template <int FMT>
 __global__ __launch_bounds__(kThreads) void k_dc_tile_sums(const void *iq, uint64_t n, double dc_a, double dc_b, double2 *tile_sums) {
     __shared__ double2 sh[kThreads];
+    __shared__ float uc8f[256];
+    if constexpr (FMT == kFmtUC8) {
+        dc_uc8_table(uc8f);
+        __syncthreads();
+    }
     const uint64_t first = (uint64_t)blockIdx.x * kDcTile + (uint64_t)threadIdx.x * kDcPerThread;
+    DcRaw<FMT> raw;
+    raw.load(iq, first, n, (uintptr_t)iq % 16 == 0);
     double zI = 0, zQ = 0;
-    for (int k = 0; k < kDcPerThread; ++k) {
-        float fI = 0, fQ = 0;  // beyond the end: zero input (the tile's sum is then not used by a later tile)
-        if (first + k < n) dc_sample<FMT>(iq, first + k, fI, fQ);
+#pragma unroll
+    for (int k = 0; k < kDcPerThread; ++k) {  // (samples beyond the end of the call only reach a sum that no later tile uses)
+        float fI, fQ;
+        raw.sample(k, uc8f, fI, fQ);
         zI = (double)fI * dc_a + zI * dc_b;
         zQ = (double)fQ * dc_a + zQ * dc_b;
     }
     double m16 = dc_b;
     for (int k = 0; k < 4; ++k) m16 *= m16;  // dc_b^16
-    const double2 v = dc_block_scan(make_double2(zI, zQ), m16, sh);
-    if (threadIdx.x == kThreads - 1) tile_sums[blockIdx.x] = v;
+    const DcScan v = dc_block_scan(make_double2(zI, zQ), m16, sh);
+    if (threadIdx.x == kThreads - 1) tile_sums[blockIdx.x] = v.incl;
 }
 
 // phase 2: state at the start of every tile; state[0] = the carried-in state, state[ntiles] = the state to carry out
@@ -1720,48 +1891,72 @@ __global__ __launch_bounds__(1024) void k_dc_scan_tiles(const double2 *tile_sums
 // phase 3: magnitudes.  sums (optional): per 131072-sample block of this call, sum(mag) and sum(magsq) as doubles.
 template <int FMT>
 __global__ __launch_bounds__(kThreads) void k_convert_dc(const void *iq, uint16_t *mag, uint64_t n, float dc_a, float dc_b, const double2 *tile_start, double *sums,
-                                                         double2 *z_out) {
+                                                         double2 *z_out, int abl) {
     __shared__ double2 sh[kThreads];
-    const uint64_t first = (uint64_t)blockIdx.x * kDcTile + (uint64_t)threadIdx.x * kDcPerThread;
-    float fI[kDcPerThread], fQ[kDcPerThread];
+    __shared__ uint4 stage[kDcTile / 8];
+    __shared__ float uc8f[256];
+    if constexpr (FMT == kFmtUC8) {
+        dc_uc8_table(uc8f);
+        __syncthreads();
+    }
+    const uint64_t tile_first = (uint64_t)blockIdx.x * kDcTile, first = tile_first + (uint64_t)threadIdx.x * kDcPerThread;
+    DcRaw<FMT> raw;
+    raw.load(iq, first, n, (uintptr_t)iq % 16 == 0);
     double zI = 0, zQ = 0;
 #pragma unroll
     for (int k = 0; k < kDcPerThread; ++k) {
-        fI[k] = fQ[k] = 0;
-        if (first + k < n) dc_sample<FMT>(iq, first + k, fI[k], fQ[k]);
-        zI = (double)fI[k] * (double)dc_a + zI * (double)dc_b;
-        zQ = (double)fQ[k] * (double)dc_a + zQ * (double)dc_b;
+        float fI, fQ;
+        raw.sample(k, uc8f, fI, fQ);
+        zI = (double)fI * (double)dc_a + zI * (double)dc_b;
+        zQ = (double)fQ * (double)dc_a + zQ * (double)dc_b;
     }
     double m16 = (double)dc_b;
     for (int k = 0; k < 4; ++k) m16 *= m16;
-    const double2 inc = dc_block_scan(make_double2(zI, zQ), m16, sh);  // state after this thread's samples, tile started from zero
+    DcScan sc;
+    sc.excl = sc.incl = make_double2(zI, zQ);
+    if (!(abl & 1)) sc = dc_block_scan(make_double2(zI, zQ), m16, sh);  // tile started from zero: state after / before this thread's samples
     // state before this thread's samples: the tile's start carried over 16 t samples, plus the threads before
     const double2 z0 = tile_start[blockIdx.x];
-    const double carry = pow(m16, (double)threadIdx.x);
-    double2 before = make_double2(z0.x * carry, z0.y * carry);
-    if (threadIdx.x > 0) {
-        const double2 p = sh[threadIdx.x - 1];
-        before.x += p.x;
-        before.y += p.y;
-    }
-    (void)inc;
+    double carry = 1.0, sq = m16;  // m16^t by the bits of t
+    for (uint32_t t = threadIdx.x; t; t >>= 1, sq *= sq)
+        if (t & 1) carry *= sq;
+    const double2 before = make_double2(z0.x * carry + sc.excl.x, z0.y * carry + sc.excl.y);
     float z1_I = (float)before.x, z1_Q = (float)before.y;
     double sl = 0, sp = 0;
+    // Full tiles leave through LDS so that a wavefront's stores cover whole cache lines: the tile's 8 KB go out as 2 x 256
+    // coalesced 16-byte stores.  The recording's last tile stores sample by sample.
+    const bool tile_out = (uintptr_t)mag % 16 == 0 && tile_first + kDcTile <= n;  // workgroup-uniform
+    const int live = (n - first >= (uint64_t)kDcPerThread || first >= n) ? (first >= n ? 0 : kDcPerThread) : (int)(n - first);  // samples of this thread inside the call
+    const int last = (first < n && n - first <= (uint64_t)kDcPerThread) ? (int)(n - 1 - first) : -1;                       // ... and the call's last sample, if it is here
+    uint32_t packed[kDcPerThread / 2];
 #pragma unroll
     for (int k = 0; k < kDcPerThread; ++k) {
-        if (first + k >= n) break;
-        float xI = fI[k], xQ = fQ[k];
+        float xI, xQ;
+        raw.sample(k, uc8f, xI, xQ);
         z1_I = xI * dc_a + z1_I * dc_b;  // convert.c:137-140
         z1_Q = xQ * dc_a + z1_Q * dc_b;
         xI -= z1_I;
         xQ -= z1_Q;
         float magsq = xI * xI + xQ * xQ;
         if (magsq > 1.0f) magsq = 1.0f;
-        const float m = sqrtf(magsq);
-        mag[first + k] = (uint16_t)(m * 65535.0f + 0.5f);
-        sl += (double)m;
-        sp += (double)magsq;
-        if (first + k == n - 1) *z_out = make_double2((double)z1_I, (double)z1_Q);  // converter_state carried to the next call
+        const float m = (abl & 4) ? magsq : sqrtf(magsq);
+        const uint32_t mv = (uint32_t)(uint16_t)(m * 65535.0f + 0.5f);
+        packed[k >> 1] = (k & 1) ? (packed[k >> 1] | (mv << 16)) : mv;
+        if (!tile_out && k < live) mag[first + k] = (uint16_t)mv;
+        if (sums && k < live) {
+            sl += (double)m;
+            sp += (double)magsq;
+        }
+        if (k == last) *z_out = make_double2((double)z1_I, (double)z1_Q);  // converter_state carried to the next call
+        __builtin_amdgcn_sched_barrier(0);  // one sample after the other (register pressure, see above)
+    }
+    if (tile_out && !(abl & 2)) {
+        stage[2 * threadIdx.x] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        stage[2 * threadIdx.x + 1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+        __syncthreads();
+        uint4 *o = (uint4 *)(mag + tile_first);
+        o[threadIdx.x] = stage[threadIdx.x];
+        o[threadIdx.x + kThreads] = stage[threadIdx.x + kThreads];
     }
     if (sums) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -1797,7 +1992,6 @@ hipError_t by_format(int fmt, F &&f) {
     }
 }
 
-inline unsigned tiles_of(uint64_t n) { return (unsigned)((n + kTile - 1) / kTile); }
 
 }  // namespace
 
@@ -1909,6 +2103,36 @@ hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *t
     });
 }
 
+// ---- Mode A/C merge: one thread per dword of a 56-byte record
+__global__ __launch_bounds__(kThreads) void k_merge_modeac(const MergeArgs m) {
+    constexpr uint32_t kDw = sizeof(rsb_message) / 4;
+    const uint32_t *src = (const uint32_t *)m.modes, *acs = (const uint32_t *)m.ac_msgs;
+    uint32_t *dst = (uint32_t *)m.dst;
+    const uint64_t total = (uint64_t)(m.n_modes + m.n_ac) * kDw;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kThreads) {
+        const uint32_t k = (uint32_t)(idx / kDw), d = (uint32_t)(idx - (uint64_t)k * kDw);
+        if (k < m.n_modes) {
+            uint32_t lo = 0, hi = m.nblocks;  // the block b with blk_first[b] <= k < blk_first[b + 1]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (m.blk_first[mid] <= k) lo = mid; else hi = mid;
+            }
+            dst[(uint64_t)(k + m.ac_before[lo]) * kDw + d] = src[(uint64_t)k * kDw + d];
+        } else {
+            const uint32_t t = k - m.n_modes;
+            dst[(uint64_t)m.ac_dst[t] * kDw + d] = acs[(uint64_t)t * kDw + d];
+        }
+    }
+}
+
+hipError_t launch_merge_modeac(const MergeArgs &m, hipStream_t s) {
+    const uint64_t total = (uint64_t)(m.n_modes + m.n_ac) * (sizeof(rsb_message) / 4);
+    if (total == 0) return hipSuccess;
+    const uint64_t g = (total + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(k_merge_modeac, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(kThreads), 0, s, m);
+    return hipGetLastError();
+}
+
 // ---- wire formats: one thread per message record (wire.hpp holds the byte-level description)
 __device__ __forceinline__ rsb_message load_message(const rsb_message *p) {
     // packed 56-byte records: 8-byte aligned, seven 64-bit loads
@@ -1971,23 +2195,26 @@ hipError_t launch_block_means_float(int fmt, const void *iq, uint64_t n, uint64_
     });
 }
 
+template <int FMT>
+static hipError_t launch_ac_kernel(const BatchArgs &a, int sums_only, hipStream_t s) {
+    auto kern = k_modeac<FMT>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AcShared));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.n + kBlock - 1) / kBlock)), dim3(kAcThreads), sizeof(AcShared), s, a, sums_only);
+    return hipGetLastError();
+}
+
 hipError_t launch_block_sums(const BatchArgs &a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     return by_format(a.fmt, [&](auto F) {
-        hipLaunchKernelGGL(k_block_sums<decltype(F)::value>, dim3(tiles_of(a.n)), dim3(kThreads), 0, s, a);
-        return hipGetLastError();
+        return launch_ac_kernel<decltype(F)::value>(a, 1, s);
     });
 }
 
 hipError_t launch_modeac(const BatchArgs &a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     return by_format(a.fmt, [&](auto F) {
-        constexpr int fmt = decltype(F)::value;
-        if (!a.block_means) hipLaunchKernelGGL(k_block_sums<fmt>, dim3(tiles_of(a.n)), dim3(kThreads), 0, s, a);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_modeac<fmt>, dim3(tiles_of(a.n)), dim3(kThreads), 0, s, a);
-        return hipGetLastError();
+        return launch_ac_kernel<decltype(F)::value>(a, 0, s);
     });
 }
 
@@ -2008,7 +2235,8 @@ hipError_t launch_convert_dc(int fmt, const void *iq, uint16_t *mag, uint64_t n,
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(k_dc_tile_sums<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, n, (double)dc_a, (double)dc_b, tile_sums);
             hipLaunchKernelGGL(k_dc_scan_tiles, dim3(1), dim3(1024), 0, s, tile_sums, tile_start, ntiles, z_state, (double)dc_b);
-            hipLaunchKernelGGL(k_convert_dc<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, mag, n, dc_a, dc_b, tile_start, block_means, z_state);
+            static const int abl = std::getenv("RSB_DC_ABL") ? std::atoi(std::getenv("RSB_DC_ABL")) : 0;  // ablation timing only
+            hipLaunchKernelGGL(k_convert_dc<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, mag, n, dc_a, dc_b, tile_start, block_means, z_state, abl);
             if (block_means) hipLaunchKernelGGL(k_dc_means, dim3((nblocks + 255) / 256), dim3(256), 0, s, block_means, n, nblocks);
             return hipGetLastError();
         }

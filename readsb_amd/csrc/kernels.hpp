@@ -136,6 +136,21 @@ struct WireArgs {
     uint32_t *off;  // n + 1 entries
     uint8_t *out;
 };
+// Mode A/C messages into the Mode S list on the device (readsb.c:883-886: each block's Mode S messages, then its Mode A/C
+// messages).  blk_first[b] = Mode S messages before block b (nblocks + 1 entries), ac_before[b] = Mode A/C messages before
+// block b, ac_dst[t] = final position of Mode A/C message t.  dst must not overlap modes.
+struct MergeArgs {
+    const rsb_message *modes;
+    uint32_t n_modes;
+    const uint32_t *blk_first;
+    const uint32_t *ac_before;
+    uint32_t nblocks;
+    const rsb_message *ac_msgs;
+    const uint32_t *ac_dst;
+    uint32_t n_ac;
+    rsb_message *dst;
+};
+hipError_t launch_merge_modeac(const MergeArgs &m, hipStream_t s);
 hipError_t launch_wire_offsets(const WireArgs &w, void *temp, size_t temp_bytes, hipStream_t s);
 hipError_t launch_wire_write(const WireArgs &w, hipStream_t s);
 // first-add tables := "never" everywhere, 0 for address 0 and the n given addresses

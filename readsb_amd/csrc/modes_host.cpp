@@ -484,4 +484,15 @@ void Replayer::merge_modeac(uint64_t g0, const std::vector<rsb_message> &msgs, c
     }
 }
 
+void Replayer::modeac_messages(uint64_t g0, size_t nblocks, std::vector<AcCand> &ac, std::vector<rsb_message> &out, uint32_t *counts) {
+    sort_by_g(ac);
+    size_t ia = 0;
+    for (size_t b = 0; b < nblocks; ++b) {
+        const uint64_t blk_start = g0 + b * kBlock;
+        const size_t before = out.size();
+        replay_modeac_block(g0, blk_start, blk_start + kBlock, ac, ia, stats_, out);
+        counts[b] = uint32_t(out.size() - before);
+    }
+}
+
 }  // namespace rsb

@@ -151,6 +151,10 @@ public:
     void merge_modeac(uint64_t g0, const std::vector<rsb_message> &msgs, const uint32_t *blk_counts, size_t nblocks,
                       std::vector<AcCand> &ac, std::vector<rsb_message> &out);
 
+    // The Mode A/C half of that merge alone: the candidates' messages after the greedy skip, in block order, and how
+    // many each block has (counts[nblocks]); the caller interleaves them with the Mode S list wherever that lives.
+    void modeac_messages(uint64_t g0, size_t nblocks, std::vector<AcCand> &ac, std::vector<rsb_message> &out, uint32_t *counts);
+
 private:
     CrcTables crc_;
     IcaoFilter filter_;
