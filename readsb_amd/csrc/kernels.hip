@@ -1425,6 +1425,92 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
 // ------------------------------------------------------------------------------------------------
 // Mode A/C
 
+// The same sums for many blocks at once.  The sequential part is two float additions per sample and block; k_block_means_float
+// spends a whole wavefront on one block's chain (v_readlane + v_add per sample: 64 blocks' chains would fit its lanes).  Here a
+// workgroup takes 60 blocks: wavefront 0 holds one block per lane and adds, in sample order, what wavefronts 1..15 computed
+// 64 samples ahead into LDS (transposed: [sample][block], row stride 61 floats = no bank conflicts on either side).
+constexpr int kMeansGroup = 60, kMeansChunk = 64, kMeansRow = 61;
+template <int FMT>
+__global__ __launch_bounds__(1024) void k_block_means_group(const void *iq, uint64_t n, uint64_t blk_len, double *means, uint32_t nblocks) {
+    if constexpr (FMT == kFmtSC16 || FMT == kFmtSC16Q11) {
+        __shared__ float buf[2][2][kMeansChunk * kMeansRow];  // [buffer][0 = mag, 1 = magsq][sample * kMeansRow + block]
+        const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const uint32_t b0 = blockIdx.x * kMeansGroup;
+        const uint32_t nchunks = (uint32_t)((blk_len + kMeansChunk - 1) / kMeansChunk);
+        constexpr float scale = (FMT == kFmtSC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+        auto length_of = [&](uint32_t blk) -> uint32_t {  // samples of block blk (0 beyond the last block)
+            if (blk >= nblocks) return 0u;
+            const uint64_t start = (uint64_t)blk * blk_len;
+            return (uint32_t)((n - start < blk_len) ? (n - start) : blk_len);
+        };
+        // wavefronts 1..15, four blocks each: the raw samples of a chunk are fetched four chunks ahead (slot = chunk % 4), so that
+        // no iteration waits for HBM; zero samples (beyond a block's end) give mag = magsq = 0
+        uint32_t pre[4][4];
+        auto fetch = [&](uint32_t c, int slot) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t blk = b0 + (wave - 1) * 4 + q, s = c * kMeansChunk + lane;
+                pre[slot][q] = (s < length_of(blk)) ? ((const uint32_t *)iq)[(uint64_t)blk * blk_len + s] : 0u;
+            }
+        };
+        auto emit = [&](int slot, uint32_t which) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t lb = (wave - 1) * 4 + q, v = pre[slot][q];
+                const float fI = (float)(short)(v & 0xffffu) * scale, fQ = (float)(short)(v >> 16) * scale;
+                float magsq = fI * fI + fQ * fQ;  // convert.c:236-243
+                if (magsq > 1.0f) magsq = 1.0f;
+                buf[which][0][lane * kMeansRow + lb] = sqrtf(magsq);
+                buf[which][1][lane * kMeansRow + lb] = magsq;
+            }
+        };
+        const uint32_t my_len = length_of(b0 + lane);  // wavefront 0: lane = block
+        float sum_level = 0, sum_power = 0;
+        auto consume = [&](uint32_t c) {
+            const float *mg = &buf[c & 1][0][lane], *pw = &buf[c & 1][1][lane];
+            const uint32_t s0 = c * kMeansChunk;
+            if (s0 + kMeansChunk <= my_len) {
+#pragma unroll 16
+                for (uint32_t k = 0; k < (uint32_t)kMeansChunk; ++k) {  // convert.c:226-262: sample order
+                    sum_power += pw[k * kMeansRow];
+                    sum_level += mg[k * kMeansRow];
+                }
+            } else {
+                for (uint32_t k = 0; k < (uint32_t)kMeansChunk && s0 + k < my_len; ++k) {
+                    sum_power += pw[k * kMeansRow];
+                    sum_level += mg[k * kMeansRow];
+                }
+            }
+        };
+        if (wave >= 1) {
+            fetch(0, 0);
+            fetch(1, 1);
+            fetch(2, 2);
+            fetch(3, 3);
+            emit(0, 0);
+            fetch(4, 0);
+        }
+        __syncthreads();
+        for (uint32_t c = 0; c < nchunks; c += 4) {  // iteration i = c + u: chunk i + 1 goes to LDS while chunk i is added
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = c + (uint32_t)u;
+                if (wave >= 1) {
+                    emit((u + 1) & 3, (i + 1) & 1);
+                    fetch(i + 5, (u + 1) & 3);
+                } else if (lane < (uint32_t)kMeansGroup && i < nchunks) {
+                    consume(i);
+                }
+                __syncthreads();
+            }
+        }
+        if (wave == 0 && lane < (uint32_t)kMeansGroup && b0 + lane < nblocks) {  // "sum / nsamples" is a float division there, widened afterwards
+            means[2 * (b0 + lane)] = (double)(sum_level / (float)my_len);
+            means[2 * (b0 + lane) + 1] = (double)(sum_power / (float)my_len);
+        }
+    }
+}
+
 // ---- Mode A/C and the block statistics it needs: one 1024-thread workgroup per 131072-sample block.
 // Pass 1 (integer formats without caller-supplied means): the block's new samples -> sum(mag), sum(mag^2) exactly as the
 // integer converters take them (convert.c:71-72,82-83,104-110).  Pass 2: the block once more (L2-resident: 256-512 KB), in
@@ -1477,7 +1563,13 @@ struct __attribute__((aligned(16))) AcShared {
 static_assert(sizeof(AcShared) <= 160 * 1024, "LDS budget of one CU");
 
 // thresholds, the 20 bits, Gillham reordering (demod_2400.c:575-639) for a position whose F1 and F2 passed
-__device__ __forceinline__ void ac_bits(const BatchArgs &a, const uint16_t *m, uint32_t j, unsigned f1_sample, uint64_t blk_start, unsigned noise_level) {
+// (out of line, called from the dense stage and from the two queue-overflow paths: inlined three times it made the kernel spill)
+struct AcOut {
+    uint32_t *count;
+    AcCand *ac;
+    uint32_t cap;
+};
+__device__ __noinline__ void ac_bits(const AcOut a, const uint16_t *m, uint32_t j, unsigned f1_sample, uint64_t blk_start, unsigned noise_level) {
     const unsigned f1_level = ((unsigned)m[j] + m[j + 1]) / 2;
     const unsigned f2_clock = ac_f2_clock(m, (int)j, f1_sample), f1_clock = f2_clock - (87 * 14);
     const int k2 = (int)j + (int)(f2_clock / 25 - f1_sample);
@@ -1511,8 +1603,8 @@ __device__ __forceinline__ void ac_bits(const BatchArgs &a, const uint16_t *m, u
         ((bits & 0x00100) ? 0x0002 : 0) | ((bits & 0x00080) ? 0x0400 : 0) | ((bits & 0x00040) ? 0x0004 : 0) |
         ((bits & 0x00004) ? 0x0080 : 0);
 
-    const uint32_t slot = atomicAdd(&a.counters[kCntAc], 1u);
-    if (slot < a.ac_cap) {
+    const uint32_t slot = atomicAdd(a.count, 1u);
+    if (slot < a.cap) {
         AcCand c;
         c.g = (uint32_t)(blk_start + f1_sample);
         c.f2_clock = f2_clock;
@@ -1595,6 +1687,7 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
 
     // ---- pass 2: tiles of kAcTile f1 positions; mt[i] = S[blk_start + t0 - 2 + i], i.e. m[j] = S[blk_start + t0 + j] = mt[j + 2]
     const uint16_t *m = mt + 2;
+    const AcOut out{&a.counters[kCntAc], a.ac, a.ac_cap};
     for (uint32_t t0 = 0; t0 < blk_len; t0 += kAcTile) {
         const int64_t q0 = (int64_t)(blk_start + t0) - 2 - (int64_t)kTrailing;  // iq index of mt[0]: a multiple of 8
         if (a.iq_aligned && q0 >= 0 && q0 + 8 * kAcChunks <= (int64_t)a.n) {
@@ -1636,7 +1729,7 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
                 if (slots[k] < (uint32_t)kAcQ1)
                     sh.q1[slots[k]] = (uint16_t)j;
                 else if (ac_f2_tests(m, j, t0 + j, noise_level))  // queue full: on the spot
-                    ac_bits(a, m, j, t0 + j, blk_start, noise_level);
+                    ac_bits(out, m, j, t0 + j, blk_start, noise_level);
             }
         }
         __syncthreads();
@@ -1660,7 +1753,7 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
                 if (slot < (uint32_t)kAcQ2)
                     sh.q2[slot] = (uint16_t)j;
                 else
-                    ac_bits(a, m, j, t0 + j, blk_start, noise_level);
+                    ac_bits(out, m, j, t0 + j, blk_start, noise_level);
             }
         }
         __syncthreads();
@@ -1668,7 +1761,7 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
         const uint32_t nq2 = min(sh.nq2, (uint32_t)kAcQ2);
         for (uint32_t ci = tid; ci < nq2; ci += kAcThreads) {  // thresholds and the 20 bits (:575-639)
             const uint32_t j = sh.q2[ci];
-            ac_bits(a, m, j, t0 + j, blk_start, noise_level);
+            ac_bits(out, m, j, t0 + j, blk_start, noise_level);
         }
         __syncthreads();
     }
@@ -2189,8 +2282,12 @@ hipError_t launch_filter_rebuild(uint32_t *t0, uint32_t *t1, const uint32_t *add
 
 hipError_t launch_block_means_float(int fmt, const void *iq, uint64_t n, uint64_t blk_len, double *means, hipStream_t s) {
     if (n == 0) return hipSuccess;
+    const uint32_t nblocks = (uint32_t)((n + blk_len - 1) / blk_len);
     return by_format(fmt, [&](auto F) {
-        hipLaunchKernelGGL(k_block_means_float<decltype(F)::value>, dim3((unsigned)((n + blk_len - 1) / blk_len)), dim3(64), 0, s, iq, n, blk_len, means);
+        if (nblocks >= 16)  // many blocks: one lane per block does the sequential sums, the other wavefronts feed it
+            hipLaunchKernelGGL(k_block_means_group<decltype(F)::value>, dim3((nblocks + kMeansGroup - 1) / kMeansGroup), dim3(1024), 0, s, iq, n, blk_len, means, nblocks);
+        else
+            hipLaunchKernelGGL(k_block_means_float<decltype(F)::value>, dim3(nblocks), dim3(64), 0, s, iq, n, blk_len, means);
         return hipGetLastError();
     });
 }

@@ -268,3 +268,21 @@ def test_exact_statistics_across_batches(built):
         assert st[k] == ref[k], k
     for k in ("signal_power_sum", "peak_signal_power", "noise_power_sum"):
         assert st[k] == float.fromhex(ref[k]), k
+
+
+@pytest.mark.parametrize("fmt", ["SC16", "SC16Q11"])
+def test_float_block_means_many_blocks(fmt, built):
+    """Mode A/C on the float formats over more than 16 blocks: the per-block float32 running sums (convert.c:226-262) then come
+    from the grouped kernel (one lane per block); every Mode A/C decision hangs on them (demod_2400.c:484-485).  Checked against
+    the oracle (itself pinned by the reference's fixtures); the last block is ragged."""
+    from readsb_amd.synth import Scenario
+
+    sc = Scenario(20 * 131072 + 3001, seed=21, fmt=fmt, modeac_per_sec=400, frames_per_sec=1500)
+    iq = generate(sc)
+    want, wst = Oracle(fmt=fmt, nfix=1, modeac=True).run_stream(iq)
+    assert wst["modeac"] > 100
+    ch = readsb_amd.Channel(fmt=fmt, fix_bits=1, mode_ac=True, max_batch_samples=1 << 22)
+    got = ch.process_host(iq)
+    assert first_mismatch(want, got.view(REC_DTYPE)) is None
+    assert ch.stats()["demod_modeac"] == wst["modeac"]
+    ch.close()
