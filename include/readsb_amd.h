@@ -72,6 +72,10 @@ typedef struct rsb_config {
  * fast path.  Implies RSB_FLAG_HOST_REPLAY. */
 #define RSB_FLAG_EXACT_STATS 2u
 
+/* rsb_submit runs the scan only; the filter-superset prune waits for rsb_collect, so that the caller can widen the superset
+ * first (rsb_superset_add).  For decoding ONE recording in shards on several GPUs; see rsb_seek. */
+#define RSB_FLAG_DEFER_PRUNE 4u
+
 /* One decoded message: the fields of struct modesMessage (readsb.h:421-439) that the hot path
  * itself produces.  Packed, 56 bytes. */
 #pragma pack(push, 1)
@@ -144,6 +148,28 @@ int rsb_filter_add(rsb_ctx *ctx, uint32_t addr);
 /* One icaoFilterExpire flip (icao_filter.c:147-161) as an explicit event between submits; the
  * reference drives it from wall-clock time, which a reproducible batch run cannot. */
 int rsb_filter_expire(rsb_ctx *ctx);
+
+/* ---- one recording in shards (no counterpart in the reference, which is one process on one core) ----
+ * A shard is a run of whole 131072-sample blocks starting anywhere in the recording.  Its scan needs nothing but its own
+ * samples and the 326 before them (the overlap of sdr_ifile.c:199-204); what couples shards is the ICAO filter
+ * (icao_filter.c; mode_s.c:717-726).  Exact decoding on N GPUs, contexts created with RSB_FLAG_DEFER_PRUNE:
+ *   1. every rank: rsb_seek to its shard, rsb_submit (scan), rsb_export_adders;
+ *   2. all-gather of the adder lists (the one collective of the path); every rank: rsb_superset_add of the union;
+ *   3. in stream order: a rank receives the filter's contents from the rank before it (rsb_filter_add each), runs
+ *      rsb_collect, and passes rsb_filter_export on.
+ * readsb_amd/dist.py: decode_recording_sharded does this over torch.distributed (RCCL).  Not available with dc_filter
+ * (the converter's DC state would have to travel as well). */
+
+/* Continue at stream position `stream_pos` (a multiple of RSB_BLOCK_SAMPLES) with `carry` = the RSB_TRAILING_SAMPLES samples
+ * before it, in the input format (host or device memory; NULL = zeros, the start of a recording).  Nothing may be pending. */
+int rsb_seek(rsb_ctx *ctx, uint64_t stream_pos, const void *carry, int carry_on_device);
+/* Every address the submitted scans (and rsb_filter_add / rsb_superset_add calls) marked as "the filter may learn this"
+ * (mode_s.c:717-726), ascending.  Waits for the pending scans.  *n_out = their number (RSB_EOVERFLOW if > cap). */
+int rsb_export_adders(rsb_ctx *ctx, uint32_t *out, size_t cap, size_t *n_out);
+/* Widen the prune's superset by these addresses (the other shards' adders).  Does not touch the filter itself. */
+int rsb_superset_add(rsb_ctx *ctx, const uint32_t *addrs, size_t n);
+/* The filter's present contents (both generations, icao_filter.c:97-119), for handing to the next shard's rsb_filter_add. */
+int rsb_filter_export(rsb_ctx *ctx, uint32_t *out, size_t cap, size_t *n_out);
 
 /* Enqueue the scan of the next `nsamples` IQ samples of this channel, resident in device memory
  * at `iq_dev` (2 bytes/sample for UC8, 4 for SC16/SC16Q11, interleaved I,Q as convert.c reads

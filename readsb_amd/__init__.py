@@ -39,6 +39,7 @@ class Config(C.Structure):
 
 FLAG_HOST_REPLAY = 1
 FLAG_EXACT_STATS = 2
+FLAG_DEFER_PRUNE = 4
 
 
 class Stats(C.Structure):
@@ -65,6 +66,10 @@ SYMBOLS = {
     "rsb_filter_add": (C.c_int, [_VP, C.c_uint32]),
     "rsb_filter_expire": (C.c_int, [_VP]),
     "rsb_submit": (C.c_int, [_VP, _VP, C.c_uint64, _VP]),
+    "rsb_seek": (C.c_int, [_VP, C.c_uint64, _VP, C.c_int]),
+    "rsb_export_adders": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
+    "rsb_superset_add": (C.c_int, [_VP, _VP, _SZ]),
+    "rsb_filter_export": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_collect": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_process": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_process_host": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
@@ -114,12 +119,12 @@ class Channel:
     """One receiver channel (rsb_ctx)."""
 
     def __init__(self, fmt="UC8", fix_bits=1, mode_ac=False, dc_filter=False, device=0, max_batch_samples=1 << 24, queue_div=0,
-                 host_replay=False, exact_stats=False):
+                 host_replay=False, exact_stats=False, defer_prune=False):
         self.l = lib()
         self.fmt = fmt
         self.bps = 2 if fmt == "UC8" else 4
         cfg = Config(FORMATS[fmt], int(dc_filter), int(fix_bits), int(mode_ac), int(device), int(queue_div), int(max_batch_samples),
-                     (FLAG_HOST_REPLAY if host_replay else 0) | (FLAG_EXACT_STATS if exact_stats else 0), 0)
+                     (FLAG_HOST_REPLAY if host_replay else 0) | (FLAG_EXACT_STATS if exact_stats else 0) | (FLAG_DEFER_PRUNE if defer_prune else 0), 0)
         h = _VP()
         rc = self.l.rsb_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -146,6 +151,34 @@ class Channel:
 
     def filter_expire(self):
         self._check(self.l.rsb_filter_expire(self.h), "rsb_filter_expire")
+
+    # ---- one recording in shards (include/readsb_amd.h, "one recording in shards")
+    def seek(self, stream_pos: int, carry: np.ndarray | None = None):
+        """continue at stream_pos with carry = the 326 samples before it (host array in the input format; None = zeros)"""
+        if carry is not None:
+            carry = np.ascontiguousarray(carry).view(np.uint8).reshape(-1)
+            assert carry.size == TRAILING * self.bps
+        self._check(self.l.rsb_seek(self.h, stream_pos, carry.ctypes.data if carry is not None else None, 0), "rsb_seek")
+
+    def export_adders(self) -> np.ndarray:
+        out = np.zeros(1 << 16, dtype=np.uint32)
+        n = _SZ()
+        rc = self.l.rsb_export_adders(self.h, out.ctypes.data, out.size, C.byref(n))
+        if rc == -4:
+            out = np.zeros(n.value, dtype=np.uint32)
+            rc = self.l.rsb_export_adders(self.h, out.ctypes.data, out.size, C.byref(n))
+        self._check(rc, "rsb_export_adders")
+        return out[:n.value].copy()
+
+    def superset_add(self, addrs: np.ndarray):
+        addrs = np.ascontiguousarray(addrs, dtype=np.uint32)
+        self._check(self.l.rsb_superset_add(self.h, addrs.ctypes.data if addrs.size else None, addrs.size), "rsb_superset_add")
+
+    def filter_export(self) -> np.ndarray:
+        out = np.zeros(2 * 4096, dtype=np.uint32)
+        n = _SZ()
+        self._check(self.l.rsb_filter_export(self.h, out.ctypes.data, out.size, C.byref(n)), "rsb_filter_export")
+        return out[:n.value].copy()
 
     def submit(self, dev_ptr: int, nsamples: int, stream: int = 0):
         self._check(self.l.rsb_submit(self.h, dev_ptr, nsamples, stream), "rsb_submit")

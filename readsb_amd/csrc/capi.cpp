@@ -75,6 +75,7 @@ int setup_device(rsb_ctx *c) {
     if (c->item_cap < 65536) c->item_cap = 65536;
     c->surv_cap = (uint32_t)(cap / 4 < 4096 ? 4096 : cap / 4);
     c->exact_stats = (c->cfg.flags & RSB_FLAG_EXACT_STATS) != 0;
+    c->defer_prune = (c->cfg.flags & RSB_FLAG_DEFER_PRUNE) != 0;
     if (c->exact_stats) c->surv_cap = (uint32_t)cap;  // every gated offset (about 1 % of the samples on noise) becomes a candidate record
     c->ac_cap = (uint32_t)(cap / 4 < 4096 ? 4096 : cap / 4);
     c->nblocks_cap = (nmax + kBlock - 1) / kBlock + 1;
@@ -312,13 +313,88 @@ int rsb_filter_expire(rsb_ctx *c) {
     return RSB_OK;
 }
 
+// the adder bitmap on the host, once every pending scan has finished writing it
+static int fetch_bitmap(rsb_ctx *c, std::vector<uint32_t> &words) {
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    for (rsb_slot &b : c->slots)
+        if (b.pending) HIP_TRY(c, hipEventSynchronize(b.ev[3]));
+    words.resize((1u << 24) / 32);
+    HIP_TRY(c, hipMemcpy(words.data(), c->d_bitmap, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RSB_OK;
+}
+
+int rsb_seek(rsb_ctx *c, uint64_t stream_pos, const void *carry, int carry_on_device) {
+    if (!c || c->block_mode) return RSB_EINVAL;
+    if (c->cfg.dc_filter) {
+        c->err = "rsb_seek: not available with dc_filter (the converter's state does not travel)";
+        return RSB_EINVAL;
+    }
+    if (c->any_pending()) {
+        c->err = "rsb_seek: a batch is pending";
+        return RSB_ESTATE;
+    }
+    if (stream_pos % kBlock != 0) {
+        c->err = "rsb_seek: stream position is not a multiple of 131072";
+        return RSB_EINVAL;
+    }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const unsigned bps = (c->cfg.input_format == RSB_UC8) ? 2 : 4, k = c->submitted % 3;
+    if (carry) HIP_TRY(c, hipMemcpy(c->d_carry[k], carry, (size_t)kTrailing * bps, carry_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    c->carry_valid[k] = carry ? 1 : 0;
+    c->stream_pos = c->submit_pos = stream_pos;
+    c->finished = c->submit_finished = false;
+    return RSB_OK;
+}
+
+int rsb_export_adders(rsb_ctx *c, uint32_t *out, size_t cap, size_t *n_out) {
+    if (!c || (!out && cap) || !n_out) return RSB_EINVAL;
+    std::vector<uint32_t> words;
+    const int rc = fetch_bitmap(c, words);
+    if (rc != RSB_OK) return rc;
+    size_t n = 0;
+    for (uint32_t w = 0; w < words.size(); ++w)
+        for (uint32_t x = words[w]; x; x &= x - 1) {
+            if (n < cap) out[n] = (w << 5) | (uint32_t)__builtin_ctz(x);
+            ++n;
+        }
+    *n_out = n;
+    if (n > cap) {
+        c->err = "rsb_export_adders: output buffer too small";
+        return RSB_EOVERFLOW;
+    }
+    return RSB_OK;
+}
+
+int rsb_superset_add(rsb_ctx *c, const uint32_t *addrs, size_t n) {
+    if (!c || (!addrs && n)) return RSB_EINVAL;
+    if (n == 0) return RSB_OK;
+    std::vector<uint32_t> words;
+    const int rc = fetch_bitmap(c, words);
+    if (rc != RSB_OK) return rc;
+    for (size_t i = 0; i < n; ++i) words[(addrs[i] & 0xffffffu) >> 5] |= 1u << (addrs[i] & 31);
+    HIP_TRY(c, hipMemcpy(c->d_bitmap, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return RSB_OK;
+}
+
+int rsb_filter_export(rsb_ctx *c, uint32_t *out, size_t cap, size_t *n_out) {
+    if (!c || (!out && cap) || !n_out) return RSB_EINVAL;
+    c->replay.filter().contents(c->h_addrs);
+    *n_out = c->h_addrs.size();
+    if (c->h_addrs.size() > cap) {
+        c->err = "rsb_filter_export: output buffer too small";
+        return RSB_EOVERFLOW;
+    }
+    if (!c->h_addrs.empty()) std::memcpy(out, c->h_addrs.data(), c->h_addrs.size() * sizeof(uint32_t));
+    return RSB_OK;
+}
+
 static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
     HIP_TRY(c, hipMemsetAsync(b.d_counters, 0, kCntAlloc * sizeof(uint32_t), s));
     HIP_TRY(c, hipMemsetAsync(b.d_region_counts, 0, (size_t)a.n_regions * sizeof(uint32_t), s));
     HIP_TRY(c, hipEventRecord(b.ev[0], s));
     if (c->run_modes) HIP_TRY(c, launch_scan(a, c->scan_grid, s));
     HIP_TRY(c, hipEventRecord(b.ev[1], s));
-    if (c->run_modes) HIP_TRY(c, launch_prune(a, s));
+    if (c->run_modes && !c->defer_prune) HIP_TRY(c, launch_prune(a, s));
     HIP_TRY(c, hipEventRecord(b.ev[2], s));
     b.means_on_device = nullptr;
     if ((c->run_ac || c->exact_stats) && nsamples) {
@@ -495,6 +571,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     // everything from here on runs on the context's own stream, behind this batch's scan and beside the next batch's
     hipStream_t s = c->replay_stream;
     HIP_TRY(c, hipStreamWaitEvent(s, b.ev[3], 0));
+    if (c->defer_prune && c->run_modes) HIP_TRY(c, launch_prune(b.pending_args, s));  // against the superset as the caller has widened it
     uint32_t cnt[kCntCount];
     HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));

@@ -67,6 +67,7 @@ struct rsb_ctx {
     int first_cur = 0;
     bool filter_dirty = true;       // the tables do not mirror replay.filter() (reset, external add / expire, host replay)
     bool host_replay_only = false;  // RSB_FLAG_HOST_REPLAY
+    bool defer_prune = false;       // RSB_FLAG_DEFER_PRUNE: k_prune runs at collect time
     bool exact_stats = false;       // RSB_FLAG_EXACT_STATS: every gated offset goes to the host replay, block means are kept
     std::vector<double> h_blk_mean_power;
     std::vector<uint64_t> h_blk_sums;

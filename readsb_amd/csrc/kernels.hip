@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(kThreads) void k_filter_fill(uint32_t *t0, uint32_t
 // the instruction stream, so no LDS window is needed -- re-slices the winning phase with the scan kernel's per-lane
 // coefficient slicer, repairs it (crc.c:410-418), fills in the fields of mode_s.c:424-562 and the signal level of
 // demod_2400.c:342-354, and writes its 56-byte record.  LDS holds only the tables: 16 wavefronts per CU.
-constexpr int kEmitWaves = 16;
+constexpr int kEmitWaves = 8;   // (16 capped the kernel at 128 VGPRs and made it spill)
 constexpr int kEmitTrios = 12;       // 3 chunks = 12 rows (24 samples) = 2 groups of five bits per step; 24 groups >= 23
 
 struct __attribute__((aligned(16))) EmitShared {
@@ -2191,7 +2191,7 @@ hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *t
                                       (int)r.n_items, s);
     if (e != hipSuccess) return e;
     return by_format(a.fmt, [&](auto F) {
-        hipLaunchKernelGGL(k_replay_emit<decltype(F)::value>, dim3(256), dim3(64 * kEmitWaves), 0, s, a, r);
+        hipLaunchKernelGGL(k_replay_emit<decltype(F)::value>, dim3(512), dim3(64 * kEmitWaves), 0, s, a, r);
         return hipGetLastError();
     });
 }

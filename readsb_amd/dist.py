@@ -66,3 +66,114 @@ def gather_messages(msgs: np.ndarray, device: torch.device) -> list[np.ndarray]:
     out = [torch.zeros_like(buf) for _ in range(n)]
     dist.all_gather(out, buf)
     return [o.cpu().numpy()[:c * MSG_DTYPE.itemsize].view(MSG_DTYPE).copy() for o, c in zip(out, counts)]
+
+
+# ---- one recording decoded in shards (include/readsb_amd.h, "one recording in shards") ----------------
+#
+# Segment k = samples [k * seg, (k + 1) * seg) of the recording, seg a multiple of 131072.  In round j rank r scans segment
+# j * world + r.  The scans of a round run in parallel; what couples the segments is the ICAO filter:
+#   * every rank's adder list is all-gathered (the path's one collective) and added to every rank's prune superset;
+#   * the sequential half then runs in stream order: a rank receives the filter's contents from the rank that holds the segment
+#     before its own, collects, and sends its filter on (point to point: a ring over the ranks, wrapping into the next round).
+
+def shard_scan(ch, start: int, nsamples: int, dev_ptr: int, carry) -> np.ndarray:
+    """step 1 on one rank: seek, scan, the shard's adder list"""
+    ch.seek(start, carry)
+    ch.submit(dev_ptr, nsamples)
+    return ch.export_adders()
+
+
+def shard_finish(ch, all_adders: np.ndarray, filter_in: np.ndarray | None, cap: int):
+    """steps 2 and 3 on one rank: widen the superset, take over the filter, collect -> (messages, filter to pass on)"""
+    ch.superset_add(all_adders)
+    if filter_in is not None:
+        for a in np.unique(filter_in):
+            ch.filter_add(int(a))
+    msgs = ch.collect(cap).copy()
+    return msgs, ch.filter_export()
+
+
+def _all_gather_u32(mine: np.ndarray, device: torch.device) -> np.ndarray:
+    """variable-length all-gather of uint32 lists -> their concatenation (on every rank)"""
+    _, n = world()
+    if n == 1:
+        return mine
+    counts = gather_counts(int(mine.size), device)
+    longest = max(1, max(counts))
+    buf = torch.zeros(longest, dtype=torch.int64, device=device)
+    if mine.size:
+        buf[:mine.size] = torch.from_numpy(mine.astype(np.int64)).to(device)
+    out = [torch.zeros_like(buf) for _ in range(n)]
+    dist.all_gather(out, buf)
+    return np.concatenate([o.cpu().numpy()[:c].astype(np.uint32) for o, c in zip(out, counts)])
+
+
+def _isend_u32(values: np.ndarray, dst: int, device: torch.device) -> list:
+    """Non-blocking (the receiver may first have to pass a collective the sender has already left: the hand-over from the
+    last rank of a round to rank 0 of the next).  -> (request, tensor) pairs to wait on / keep alive."""
+    size = torch.tensor([values.size], dtype=torch.int64, device=device)
+    pending = [(dist.isend(size, dst), size)]
+    if values.size:
+        data = torch.from_numpy(values.astype(np.int64)).to(device)
+        pending.append((dist.isend(data, dst), data))
+    return pending
+
+
+def _recv_u32(src: int, device: torch.device) -> np.ndarray:
+    n = torch.zeros(1, dtype=torch.int64, device=device)
+    dist.recv(n, src)
+    if int(n.item()) == 0:
+        return np.zeros(0, dtype=np.uint32)
+    buf = torch.zeros(int(n.item()), dtype=torch.int64, device=device)
+    dist.recv(buf, src)
+    return buf.cpu().numpy().astype(np.uint32)
+
+
+def decode_recording_sharded(ch, total_samples: int, segment_samples: int, get_segment, get_carry, device: torch.device, cap: int = 1 << 20):
+    """Decode ONE recording on all ranks.  ch: this rank's Channel, created with defer_prune=True (or anything with its
+    seek / submit / export_adders / superset_add / filter_add / collect / filter_export methods).
+    get_segment(start, stop) -> device pointer of samples [start, stop) resident on this rank's GPU;
+    get_carry(start) -> host array of the 326 samples before start (None at 0).
+    -> list of (segment index, messages) of this rank's segments; all ranks' lists in segment order = the reference's output."""
+    from . import BLOCK
+
+    assert segment_samples % BLOCK == 0 and segment_samples > 0
+    rank, n = world()
+    nseg = (total_samples + segment_samples - 1) // segment_samples
+    mine, pending = [], []
+    for j in range((nseg + n - 1) // n):
+        k = j * n + rank
+        adders = np.zeros(0, dtype=np.uint32)
+        if k < nseg:
+            start, stop = k * segment_samples, min(total_samples, (k + 1) * segment_samples)
+            adders = shard_scan(ch, start, stop - start, get_segment(start, stop), get_carry(start))
+        union = _all_gather_u32(adders, device)
+        if k < nseg:
+            filter_in = _recv_u32((rank - 1) % n, device) if (k >= 1 and n > 1) else None
+            msgs, flt = shard_finish(ch, union, filter_in, cap)
+            mine.append((k, msgs))
+            if k + 1 < nseg and n > 1:
+                for req, _ in pending:
+                    req.wait()
+                pending = _isend_u32(flt, (rank + 1) % n, device)
+    for req, _ in pending:
+        req.wait()
+    return mine
+
+
+def simulate_sharded(chs, total_samples: int, segment_samples: int, get_segment, get_carry, cap: int = 1 << 20) -> np.ndarray:
+    """The same schedule with len(chs) channels in one process and no torch.distributed (tests on one GPU): 'rank' r is chs[r]."""
+    n = len(chs)
+    nseg = (total_samples + segment_samples - 1) // segment_samples
+    out, flt = [], None
+    for j in range((nseg + n - 1) // n):
+        ks = [k for k in range(j * n, (j + 1) * n) if k < nseg]
+        adders = []
+        for k in ks:
+            start, stop = k * segment_samples, min(total_samples, (k + 1) * segment_samples)
+            adders.append(shard_scan(chs[k % n], start, stop - start, get_segment(start, stop), get_carry(start)))
+        union = np.concatenate(adders) if adders else np.zeros(0, dtype=np.uint32)
+        for k in ks:
+            msgs, flt = shard_finish(chs[k % n], union, flt if k >= 1 else None, cap)
+            out.append(msgs)
+    return np.concatenate(out) if out else np.zeros(0, dtype=MSG_DTYPE)

@@ -58,3 +58,83 @@ def test_two_ranks_two_channels(tmp_path, built):
             assert np.array_equal(z[r][f"ch{ch}"], z[ch]["mine"])
         assert list(z[r]["empty_sizes"]) == [0, 3]
     assert not np.array_equal(z[0]["mine"][:56], z[1]["mine"][:56])  # channels are different recordings
+
+
+class _FakeChannel:
+    """Stands in for readsb_amd.Channel (no GPU here): one 'message' per segment that records what the filter and the prune
+    superset held when the segment was replayed; every segment teaches the filter one address."""
+
+    def __init__(self):
+        self.filter, self.superset, self.pending, self.start = set(), set(), None, None
+
+    def seek(self, start, carry):
+        assert (carry is None) == (start == 0)
+        assert carry is None or int(carry[0]) == start % 251  # the carry of THIS position
+        self.start = start
+
+    def submit(self, ptr, n):
+        assert ptr == 7_000_000 + self.start
+        self.pending = (self.start, n)
+
+    def export_adders(self):
+        return np.array([1000 + self.start // 131072], dtype=np.uint32)
+
+    def superset_add(self, addrs):
+        self.superset |= set(int(a) for a in addrs)
+
+    def filter_add(self, a):
+        self.filter.add(int(a))
+
+    def collect(self, cap):
+        import readsb_amd
+
+        start, n = self.pending
+        rec = np.zeros(1, dtype=readsb_amd.MSG_DTYPE)
+        rec["ts"], rec["addr"], rec["crc"], rec["score"] = start, len(self.filter), len(self.superset), n
+        self.filter.add(1000 + start // 131072)
+        return rec
+
+    def filter_export(self):
+        return np.array(sorted(self.filter), dtype=np.uint32)
+
+
+def _shard_rank_main(rank, world, port, outdir, nseg, total):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from readsb_amd import dist as rd
+
+    mine = rd.decode_recording_sharded(_FakeChannel(), total, 131072, get_segment=lambda a, b: 7_000_000 + a,
+                                       get_carry=lambda a: np.full(326, a % 251, dtype=np.uint8) if a else None,
+                                       device=torch.device("cpu"))
+    np.savez(os.path.join(outdir, f"shard{rank}.npz"), k=np.array([k for k, _ in mine]),
+             msgs=np.concatenate([m for _, m in mine]).view(np.uint8) if mine else np.zeros(0, np.uint8))
+    rd.barrier(torch.device("cpu"))
+    dist.destroy_process_group()
+
+
+def test_one_recording_sharded_over_ranks(tmp_path, built):
+    """the schedule of readsb_amd/dist.py: decode_recording_sharded over gloo: segments round-robin over the ranks, adder lists
+    all-gathered per round, the filter handed on in stream order (ring, wrapping into the next round), a last round with an
+    idle rank and a ragged last segment"""
+    import readsb_amd
+
+    for world, nseg in ((2, 5), (3, 4)):
+        total = (nseg - 1) * 131072 + 1000
+        out = tmp_path / f"w{world}"
+        out.mkdir()
+        mp.spawn(_shard_rank_main, args=(world, _free_port(), str(out), nseg, total), nprocs=world, join=True)
+        seen = {}
+        for r in range(world):
+            z = np.load(out / f"shard{r}.npz")
+            msgs = z["msgs"].view(readsb_amd.MSG_DTYPE)
+            assert list(z["k"]) == list(range(r, nseg, world))      # round-robin
+            for k, m in zip(z["k"], msgs):
+                seen[int(k)] = m
+        assert sorted(seen) == list(range(nseg))
+        for k in range(nseg):
+            m = seen[k]
+            assert int(m["ts"]) == k * 131072
+            assert int(m["addr"]) == k                               # the filter held exactly the earlier segments' addresses
+            assert int(m["crc"]) == min(nseg, (k // world + 1) * world)  # the superset: every segment of the rounds so far
+            assert int(m["score"]) == (1000 if k == nseg - 1 else 131072)

@@ -286,3 +286,40 @@ def test_float_block_means_many_blocks(fmt, built):
     assert first_mismatch(want, got.view(REC_DTYPE)) is None
     assert ch.stats()["demod_modeac"] == wst["modeac"]
     ch.close()
+
+
+@pytest.mark.parametrize("nranks,seg_blocks", [(2, 3), (3, 2), (4, 1)])
+def test_one_recording_in_shards(nranks, seg_blocks, built):
+    """SURVEY.md 8e, second form: ONE recording cut at multiples of 131072 and decoded by several channels ('ranks'), each
+    scanning its segments alone; adder lists exchanged, filter handed on in stream order (readsb_amd/dist.py).  The
+    concatenated output must be the unsharded one, bit for bit -- including messages that only decode because an EARLIER
+    segment taught the filter their address (DF4/5/20/21, mode_s.c:461,541), and frames that straddle a cut."""
+    import torch
+
+    from readsb_amd import dist as rd
+    from readsb_amd.synth import Scenario
+
+    sc = Scenario(13 * 131072 + 777, seed=31, frames_per_sec=3000)
+    iq = generate(sc)
+    want, _ = Oracle(fmt="UC8", nfix=1).run_stream(iq)
+    n = sc.n_samples
+    dev_iq = torch.from_numpy(iq).cuda()
+    chs = [readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=seg_blocks * 131072, defer_prune=True) for _ in range(nranks)]
+    got = rd.simulate_sharded(chs, n, seg_blocks * 131072,
+                              get_segment=lambda a, b: dev_iq.data_ptr() + 2 * a,
+                              get_carry=lambda a: iq[a - 326:a] if a else None)
+    assert first_mismatch(want, got.view(REC_DTYPE)) is None
+    # control: the filter coupling is real in this recording -- the same segments decoded WITHOUT the hand-over (every
+    # segment starting from an empty filter) lose messages whose address an earlier segment had taught the filter
+    ap = np.isin(want["msgtype"], (0, 4, 5, 16, 20, 21))
+    assert ap.sum() > 20
+    seg, alone = seg_blocks * 131072, []
+    for ch in chs:
+        ch.close()
+    for k in range((n + seg - 1) // seg):
+        a, b = k * seg, min(n, (k + 1) * seg)
+        ch = readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=seg, defer_prune=True)
+        adders = rd.shard_scan(ch, a, b - a, dev_iq.data_ptr() + 2 * a, iq[a - 326:a] if a else None)
+        alone.append(rd.shard_finish(ch, adders, None, 1 << 20)[0])
+        ch.close()
+    assert sum(m.size for m in alone) < want.size
