@@ -100,6 +100,8 @@ int setup_device(rsb_ctx *c) {
         for (hipEvent_t &ev : b.ev) HIP_TRY(c, hipEventCreate(&ev));
     }
     HIP_TRY(c, hipStreamCreateWithFlags(&c->replay_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t &ev : c->ev_part) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (void *&p : c->d_carry) HIP_TRY(c, hipMalloc(&p, kTrailing * 4));
     c->sort_temp_bytes = sort_temp_bytes(c->surv_item_cap);
     HIP_TRY(c, hipMalloc(&c->d_sort_temp, c->sort_temp_bytes));
@@ -154,7 +156,10 @@ constexpr int kMaxReplayIterations = 16;
 
 // Returns 1 when the batch was replayed on the device (messages in c->d_surv as rsb_message records,
 // counters in cnt), 0 when the host path has to take it, < 0 on error.
-int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint32_t cnt[kCntCount]) {
+// direct_out (optional): the caller's record buffer.  The message list is then emitted in parts and every finished part is
+// copied out on the copy stream beside the emit kernel of the next one (*direct = 1; the caller waits for c->copy_stream).
+int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint32_t cnt[kCntCount], rsb_message *direct_out = nullptr,
+                  size_t direct_cap = 0, int *direct = nullptr) {
     const BatchArgs &a = b.pending_args;
     int rc;
     if (c->filter_dirty && (rc = mirror_filter(c, s)) != RSB_OK) return rc;
@@ -199,7 +204,32 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
         c->filter_dirty = true;
         return 0;
     }
-    HIP_TRY(c, launch_replay_finish(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
+    HIP_TRY(c, launch_replay_select(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
+    bool parts_out = false;
+    if (direct_out && direct) {
+        uint32_t nacc = 0;
+        HIP_TRY(c, hipMemcpyAsync(&nacc, b.d_counters + kCntAccepted, sizeof(nacc), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (nacc > 0 && nacc <= r.out_cap && nacc <= direct_cap) {
+            const uint32_t chunk = ((nacc + rsb_ctx::kEmitParts - 1) / rsb_ctx::kEmitParts + 63u) & ~63u;
+            int p = 0;
+            for (uint32_t lo = 0; lo < nacc; lo += chunk, ++p) {
+                ReplayArgs part = r;
+                part.emit_lo = lo;
+                part.emit_hi = lo + chunk < nacc ? lo + chunk : nacc;
+                HIP_TRY(c, launch_replay_emit(a, part, s));
+                HIP_TRY(c, hipEventRecord(c->ev_part[p], s));
+                HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_part[p], 0));
+                HIP_TRY(c, hipMemcpyAsync(direct_out + lo, r.out + lo, (size_t)(part.emit_hi - lo) * sizeof(rsb_message), hipMemcpyDeviceToHost, c->copy_stream));
+            }
+            parts_out = true;
+        }
+    }
+    if (!parts_out) {
+        ReplayArgs all = r;
+        all.emit_lo = all.emit_hi = 0;
+        HIP_TRY(c, launch_replay_emit(a, all, s));
+    }
     HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(c->h_blk_counts.data(), c->d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -210,6 +240,7 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
         c->filter_dirty = true;
         return 0;
     }
+    if (direct) *direct = parts_out ? 1 : 0;
     if (nnew) {
         c->h_new_adders.resize(nnew);
         HIP_TRY(c, hipMemcpy(c->h_new_adders.data(), c->d_new_adders, nnew * sizeof(uint2), hipMemcpyDeviceToHost));
@@ -266,6 +297,9 @@ void rsb_destroy(rsb_ctx *c) {
             if (ev) (void)hipEventDestroy(ev);
     }
     if (c->replay_stream) (void)hipStreamDestroy(c->replay_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (hipEvent_t ev : c->ev_part)
+        if (ev) (void)hipEventDestroy(ev);
     for (void *p : c->d_carry)
         if (p) (void)hipFree(p);
     for (void *p : ptrs)
@@ -606,15 +640,21 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     // the sequential half: on the device, unless asked otherwise or the device path declines the batch
     const size_t nblocks = (size_t)((b.pending_n + kBlock - 1) / kBlock);
     c->h_blk_counts.resize(nblocks + 1);
-    int on_device = 0;
+    int on_device = 0, direct_parts = 0;
     c->timing.replay_iterations = 0;
     if (!c->run_modes) {
         on_device = 1;  // nothing to replay: a Mode A/C only pass of the drop-in
         std::memset(cnt + kCntChanged, 0, (kCntCount - kCntChanged) * sizeof(uint32_t));
         c->h_blk_counts.assign(nblocks + 1, 0);
     } else if (!c->host_replay_only && !a.emit_dead && !a.keep_all) {
-        on_device = device_replay(c, b, n_items, s, cnt);
+        // records wanted and nothing to interleave: the list can leave in parts while it is still being written
+        const bool parts_ok = !wire && out && cnt[kCntAc] == 0;
+        on_device = device_replay(c, b, n_items, s, cnt, parts_ok ? out : nullptr, cap, &direct_parts);
         if (on_device < 0) return on_device;
+        if (!on_device) {
+            HIP_TRY(c, hipStreamSynchronize(c->copy_stream));  // parts already under way: the host path rewrites the buffer afterwards
+            direct_parts = 0;
+        }
     }
     uint32_t nsurv = 0;
     if (!on_device) {
@@ -658,7 +698,12 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
             if (rc < 0) return rc;
             on_dev_list = rc == 1;
         }
-        if (on_dev_list && wire) {
+        if (direct_parts) {
+            // the parts are on their way (or there): wait for the last one
+            n = nlist;
+            HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+            delivered = true;
+        } else if (on_dev_list && wire) {
             // encode where the records are, only the wire bytes cross PCIe
             n = nlist;
             const int rc = device_wire(c, list, (uint32_t)nlist, *wire, s);

@@ -105,6 +105,9 @@ struct rsb_ctx {
     bool any_pending() const { return submitted != collected; }
     uint64_t last_n = 0;              // samples of the last collected batch
     hipStream_t replay_stream = nullptr;  // sort / replay / copy-out run here, behind the batch's scan (event) and beside the next one's
+    hipStream_t copy_stream = nullptr;    // device -> host copies of finished parts of the message list, beside the emit kernel of the next part
+    static constexpr int kEmitParts = 4;
+    hipEvent_t ev_part[kEmitParts] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t stream_pos = 0;          // of the next batch to collect
     uint64_t submit_pos = 0;          // of the next batch to submit
     bool finished = false, submit_finished = false;

@@ -1256,11 +1256,13 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
     const uint32_t lane = threadIdx.x & 63;
     uint32_t nacc = a.counters[kCntAccepted];
     if (nacc > r.out_cap) nacc = r.out_cap;
+    const uint32_t first = r.emit_hi ? r.emit_lo : 0u;  // a multiple of 64
+    if (r.emit_hi && r.emit_hi < nacc) nacc = r.emit_hi;
     uint32_t by_errors[3] = {0, 0, 0};  // wave-uniform
     constexpr int kRawVecs = (FMT == kFmtUC8 || FMT == kFmtMag16) ? 1 : 2;
     constexpr int kBps = 2 * kRawVecs;
     const uint32_t nthreads = gridDim.x * kT;
-    for (uint32_t base = (blockIdx.x * kT + threadIdx.x) & ~63u; base < nacc; base += nthreads) {
+    for (uint32_t base = first + ((blockIdx.x * kT + threadIdx.x) & ~63u); base < nacc; base += nthreads) {
         const uint32_t mi = base + lane;
         const bool valid = mi < nacc;
         uint32_t g = 0, phase = 0, info = kComboDf17 << 27, score = 0;
@@ -2180,20 +2182,38 @@ hipError_t launch_replay_reset(const BatchArgs &, const ReplayArgs &r, uint32_t 
     return hipGetLastError();
 }
 
-hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s) {
+hipError_t launch_replay_select(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s) {
     hipError_t e = hipMemsetAsync(&a.counters[kCntAccepted], 0, 5 * sizeof(uint32_t), s);  // accepted, new adders, by errors
     if (e != hipSuccess || r.n_items == 0) return e;
     hipLaunchKernelGGL(k_replay_list, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, a.counters);
     hipLaunchKernelGGL(k_replay_fold, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = hipcub::DeviceSelect::Flagged(temp, temp_bytes, hipcub::CountingInputIterator<uint32_t>(0), r.acc, r.acc_idx, &a.counters[kCntAccepted],
-                                      (int)r.n_items, s);
-    if (e != hipSuccess) return e;
+    return hipcub::DeviceSelect::Flagged(temp, temp_bytes, hipcub::CountingInputIterator<uint32_t>(0), r.acc, r.acc_idx, &a.counters[kCntAccepted],
+                                         (int)r.n_items, s);
+}
+
+hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream_t s) {
+    if (r.n_items == 0) return hipSuccess;
+    // a part of the list gets a part of the grid (every workgroup first builds its 40 KB of LDS tables)
+    const uint32_t span = r.emit_hi ? r.emit_hi - r.emit_lo : 0xffffffffu;
+    unsigned grid = 512;
+    if (span != 0xffffffffu) {
+        grid = (span + 64 * kEmitWaves * 4 - 1) / (64 * kEmitWaves * 4);
+        grid = grid < 1 ? 1 : (grid > 512 ? 512 : grid);
+    }
     return by_format(a.fmt, [&](auto F) {
-        hipLaunchKernelGGL(k_replay_emit<decltype(F)::value>, dim3(512), dim3(64 * kEmitWaves), 0, s, a, r);
+        hipLaunchKernelGGL(k_replay_emit<decltype(F)::value>, dim3(grid), dim3(64 * kEmitWaves), 0, s, a, r);
         return hipGetLastError();
     });
+}
+
+hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s) {
+    const hipError_t e = launch_replay_select(a, r, temp, temp_bytes, s);
+    if (e != hipSuccess) return e;
+    ReplayArgs all = r;
+    all.emit_lo = all.emit_hi = 0;
+    return launch_replay_emit(a, all, s);
 }
 
 // ---- Mode A/C merge: one thread per dword of a 56-byte record

@@ -109,6 +109,7 @@ struct ReplayArgs {
     rsb_message *out;
     uint32_t out_cap;
     uint64_t g0;             // stream position of the batch
+    uint32_t emit_lo, emit_hi;  // k_replay_emit: the range of accepted messages this launch writes (emit_hi = 0: all of them)
 };
 constexpr uint32_t kNever = 0xffffffffu;
 
@@ -126,6 +127,10 @@ hipError_t launch_replay_bounds(const ReplayArgs &r, hipStream_t s);  // once pe
 hipError_t launch_replay_iteration(const BatchArgs &a, const ReplayArgs &r, hipStream_t s);
 hipError_t launch_replay_reset(const BatchArgs &a, const ReplayArgs &r, uint32_t *table, hipStream_t s);
 hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s);
+// the two halves of launch_replay_finish on their own: the list of accepted items (count -> counters[kCntAccepted]), and the
+// records of the messages [r.emit_lo, r.emit_hi) of that list (so that a caller can copy finished ranges out meanwhile)
+hipError_t launch_replay_select(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s);
+hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream_t s);
 // wire formats (wire.hpp) of n message records on the device: launch_wire_offsets leaves the byte offset of message i in
 // off[i] and the total in off[n]; launch_wire_write stores the bytes at out + off[i]
 struct WireArgs {
