@@ -213,7 +213,7 @@ def main() -> int:
             workload = f"configs[4]: {args.format}, {'dense low-SNR traffic' if args.dense else 'mixed SNR'}, fix_bits {args.fix_bits}" + \
                 (", demodulate2400AC" if args.modeac else "")
         else:
-            workload = f"configs[2]: {args.format} (4-byte samples)" + (" with the DC-block IIR as a chunked scan" if args.dcfilter else ", no DC filter")
+            workload = f"configs[2]: {args.format} ({bps}-byte samples)" + (" with the DC-block IIR as a chunked scan" if args.dcfilter else ", no DC filter")
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/hbm_traffic.py from rocprofv3 --pmc passes
         if os.path.exists(tfile):
@@ -222,7 +222,8 @@ def main() -> int:
             if t.get("samples") == n and args.format == "UC8" and not args.dcfilter:
                 traffic = t.get("bytes_per_launch")
         scan_s = float(np.mean(scan_ms)) / 1e3
-        achieved = float(bps) * n / scan_s / 1e9
+        scan_bps = 2 if args.dcfilter else bps  # --dcfilter: the scan kernel reads the converter's 16-bit magnitudes
+        achieved = float(scan_bps) * n / scan_s / 1e9
         st = ch.stats()
         out = {
             "metric": "Msamples/s demod+CRC (UC8 @2.4MS/s)",
@@ -246,7 +247,7 @@ def main() -> int:
                        **({"wire_bytes_per_step": int(wire_bytes.size), "wire_check": wire_check} if wire_check else {})},
             "roofline": {"bound": "hbm", "kernel": f"k_scan<{'Mag16' if args.dcfilter else args.format}>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bps * n // (len(cuts) - 1), "avg_launch_ms": scan_s * 1e3 / (len(cuts) - 1),
+                         "algorithmic_bytes_per_launch": scan_bps * n // (len(cuts) - 1), "avg_launch_ms": scan_s * 1e3 / (len(cuts) - 1),
                          "note": "per k_scan launch (one batch); the launches of a step together read the whole recording once"},
             "stage_ms": {"scan": float(np.mean(tm["scan_ms"])), "prune": float(np.mean(tm["prune_ms"])), "modeac": float(np.mean(tm["modeac_ms"])),
                          "sort": float(np.mean(tm["sort_ms"])),

@@ -1,20 +1,25 @@
 // kernels.hip -- gfx950 kernels of the receive path.
 //
-//   k_scan      persistent workgroups; per 8192-offset tile: convert.c (IQ -> magnitude through a
-//               folded 32 KB LUT in LDS, magnitudes live in LDS only) -> demod_2400.c:109-155 as
-//               bit-parallel wavefront ballots (edge patterns of 64 lanes x 8 offsets per scalar op)
-//               -> :158-172 on the ~5 % that survive -> :179-286 five trial phases, first the DF
-//               field, then dense 56-/112-bit slicing by length class -> crc.c:67-82 / :383-406 ->
-//               the filter-independent half of mode_s.c:311-409.  Emits one 8-byte item per trial
-//               phase that can still score >= 0 under some filter state, and marks every address the
+//   k_scan      persistent workgroups, every wavefront on strips of 2768 scan offsets: convert.c (IQ -> magnitude
+//               through a folded 32 KB LUT in LDS, magnitudes live in LDS only) -> demod_2400.c:109-155 as bit-sliced
+//               edge patterns (4 offsets x 6 passes per lane and instruction) -> :158-172 on the ~5 % that
+//               survive -> :179-286 five trial phases, first the DF field, then dense 56-/112-bit slicing, one lane per
+//               frame -> crc.c:67-82 / :383-406 -> the filter-independent half of mode_s.c:311-409.  Emits one 8-byte
+//               item per trial phase that can still score >= 0 under some filter state, and marks every address the
 //               filter could ever learn (mode_s.c:717-726) in a 2^24-bit set.
 //   k_prune     drops items that need a filter member which is not in that superset (safe: such a
 //               phase scores < 0 whatever happened before it; demod_2400.c:290,304-310).
-//   sort/unique hipCUB radix sort of the kept items by (offset, phase); distinct offsets ascending.
-//   k_finalize  re-slices those few offsets into full records (5 x 14 message bytes + the signal
-//               power sums of demod_2400.c:345-351) for the host replay.
-//   k_block_sums / k_modeac   convert.c:71-83 block statistics and demod_2400.c:476-622.
-//   k_convert   the stand-alone iq_convert_fn (magnitudes written to HBM) for the drop-in converter.
+//   sort        hipCUB radix sort of the kept items by (offset, phase).
+//   k_replay_*  the sequential rules on the device (demod_2400.c:289-374): per-block greedy walk, the ICAO filter as a
+//               fixed point over a "first added at" table, k_replay_emit writes the rsb_message records.
+//   k_finalize  (host-replay path) re-slices the kept offsets into full records (5 x 14 message bytes + the signal
+//               power sums of demod_2400.c:345-351).
+//   k_modeac    one workgroup per 131072-sample block: convert.c:71-83 block sums, then demod_2400.c:476-622 in three
+//               compacted stages; k_block_means_float / k_block_means_group: the float converters' sequential sums;
+//               k_merge_modeac: Mode A/C messages into the Mode S list.
+//   k_convert   the stand-alone iq_convert_fn (magnitudes written to HBM) for the drop-in converter;
+//   k_dc_*, k_convert_dc   the --dcfilter converters as a chunked linear-recurrence scan.
+//   k_wire_*    Beast / raw encoders.
 //
 // Compiled with -ffp-contract=off: every float/double product and sum below rounds on its own, as
 // in the reference's x86-64 build.
