@@ -73,6 +73,36 @@ def cpu_baseline(seg: np.ndarray, budget_s: float = 12.0, fmt: str = "UC8", nfix
             "sample": f"{n}-sample segment of the same recording x {reps} passes (oracle/modes_oracle.c)"}
 
 
+def cpu_baseline_sharded(seg: np.ndarray, single: dict, budget_s: float = 6.0, fmt: str = "UC8", nfix: int = 1, modeac: bool = False,
+                         dc: bool = False):
+    """The reference's path sharded the way the GPUs are: one independent channel per core, every core running the
+    unmodified reference on its own copy of the segment at the same time.  value = all cores' samples / wall time."""
+    import subprocess
+
+    from oracle.oracle import REF_BIN, RefHarness
+
+    if not RefHarness.available():
+        return None
+    cores = max(1, min(16, len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16"))))  # the box's CPU share
+    n = seg.shape[0]
+    reps = max(1, int(budget_s * single["value"] * 1e6 / n))
+    with tempfile.NamedTemporaryFile(suffix=".iq", delete=False) as f:
+        seg.tofile(f)
+        path = f.name
+    try:
+        cmd = [REF_BIN, "time", fmt, str(int(nfix)), str(int(modeac)), str(int(dc)), path, str(reps)]
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(cores)]
+        ok = all(p.wait() == 0 for p in procs)
+        dt = time.perf_counter() - t0
+    finally:
+        os.unlink(path)
+    if not ok:
+        return None
+    return {"value": n * reps * cores / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "reference",
+            "sample": f"{cores} processes at once (one channel per core), each {reps} passes over the {n}-sample segment; wall time incl. process start"}
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,6 +287,9 @@ def main() -> int:
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seg, fmt=args.format, nfix=args.fix_bits, modeac=args.modeac, dc=args.dcfilter)
+            sharded = cpu_baseline_sharded(seg, out["cpu_baseline"], fmt=args.format, nfix=args.fix_bits, modeac=args.modeac, dc=args.dcfilter)
+            if sharded:
+                out["cpu_baseline_sharded"] = sharded  # north_star: "single-threaded and per-core-sharded reference CPU path ... core count stated"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

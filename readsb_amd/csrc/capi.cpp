@@ -182,6 +182,8 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
     c->timing.replay_iterations = 0;
     std::memset(cnt + kCntChanged, 0, (kCntCount - kCntChanged) * sizeof(uint32_t));
     if (r.nblocks == 0) return 1;
+    r.t_cur = c->d_first_add[c->first_cur];  // seeded with the optimistic "first added at" entries (k_replay_seed)
+    r.t_next = c->d_first_add[c->first_cur ^ 1];
     HIP_TRY(c, launch_replay_bounds(r, s));
     bool converged = false;
     for (int it = 0; it < kMaxReplayIterations && !converged; ++it) {

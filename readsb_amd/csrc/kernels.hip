@@ -1171,6 +1171,20 @@ __global__ __launch_bounds__(kThreads) void k_replay_adds(const ReplayArgs r) {
     }
 }
 
+// The starting point of the fixed-point iteration: every item that could add its address is assumed to do so ("first added
+// at" = the first such item of the address).  That is what nearly always happens -- the first clean DF17 / DF11 of an aircraft
+// is accepted unless it lies in another message's skip window -- so the first walk usually reproduces this table and the
+// iteration ends after one round instead of two.  Any fixed point is the reference's result (by induction over the offsets:
+// what happens at offset g depends only on entries below g), so the starting point affects the number of rounds only.
+__global__ __launch_bounds__(kThreads) void k_replay_seed(const ReplayArgs r) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads) {
+        const uint32_t info = r.info[i];
+        if (!combo_adds(item_combo(info))) continue;
+        const uint32_t v = item_value(info), g1 = (uint32_t)(r.keys[i] >> 3) + 1;
+        if (r.t_cur[v] > g1) atomicMin(&r.t_cur[v], g1);
+    }
+}
+
 // over the items that can add an address: did the table move / reset / list / fold
 __global__ __launch_bounds__(kThreads) void k_replay_compare(const ReplayArgs r, uint32_t *changed) {
     bool any = false;
@@ -2169,6 +2183,7 @@ inline unsigned item_grid(uint32_t n) {
 
 hipError_t launch_replay_bounds(const ReplayArgs &r, hipStream_t s) {
     hipLaunchKernelGGL(k_replay_bounds, dim3(item_grid(r.n_items + 1)), dim3(kThreads), 0, s, r);
+    if (r.n_items && r.t_cur) hipLaunchKernelGGL(k_replay_seed, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);
     return hipGetLastError();
 }
 
