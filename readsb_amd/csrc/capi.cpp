@@ -100,8 +100,6 @@ int setup_device(rsb_ctx *c) {
         for (hipEvent_t &ev : b.ev) HIP_TRY(c, hipEventCreate(&ev));
     }
     HIP_TRY(c, hipStreamCreateWithFlags(&c->replay_stream, hipStreamNonBlocking));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    for (hipEvent_t &ev : c->ev_part) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (void *&p : c->d_carry) HIP_TRY(c, hipMalloc(&p, kTrailing * 4));
     c->sort_temp_bytes = sort_temp_bytes(c->surv_item_cap);
     HIP_TRY(c, hipMalloc(&c->d_sort_temp, c->sort_temp_bytes));
@@ -122,7 +120,7 @@ int setup_device(rsb_ctx *c) {
         HIP_TRY(c, hipMalloc((void **)&c->d_blk_counts, c->nblocks_cap * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_blk_start, (c->nblocks_cap + 1) * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_new_adders, rsb_ctx::kNewAddersCap * sizeof(uint2)));
-        HIP_TRY(c, hipMalloc((void **)&c->d_addr_upload, 2 * IcaoFilter::kSlots * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_addr_upload, 8 * IcaoFilter::kSlots * sizeof(uint32_t)));  // 2 x kSlots members, up to 6 x kSlots stale entries
         // the message records of the device replay reuse the candidate records' memory (one path runs per batch)
         c->out_cap = (uint32_t)((size_t)c->surv_cap * sizeof(Survivor) / sizeof(rsb_message));
     }
@@ -143,10 +141,19 @@ int reset_device(rsb_ctx *c) {
 // first-add tables := the host filter's contents (both generations, icao_filter.c:97-119)
 int mirror_filter(rsb_ctx *c, hipStream_t s) {
     c->replay.filter().contents(c->h_addrs);
-    const uint32_t n = (uint32_t)c->h_addrs.size();
-    if (n) HIP_TRY(c, hipMemcpyAsync(c->d_addr_upload, c->h_addrs.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, launch_filter_rebuild(c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, n, s));
-    HIP_TRY(c, hipStreamSynchronize(s));  // h_addrs is pageable
+    const uint32_t n = (uint32_t)c->h_addrs.size(), n_stale = (uint32_t)c->table_members.size();
+    uint32_t *members_dev = c->d_addr_upload, *stale_dev = c->d_addr_upload + 2 * IcaoFilter::kSlots;
+    if (n) HIP_TRY(c, hipMemcpyAsync(members_dev, c->h_addrs.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (c->tables_valid && n_stale <= 6 * IcaoFilter::kSlots) {
+        // the tables only differ from "never" at the listed entries: undo those, set the present members
+        if (n_stale) HIP_TRY(c, hipMemcpyAsync(stale_dev, c->table_members.data(), n_stale * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, launch_filter_update(c->d_first_add[0], c->d_first_add[1], stale_dev, n_stale, members_dev, n, s));
+    } else {
+        HIP_TRY(c, launch_filter_rebuild(c->d_first_add[0], c->d_first_add[1], members_dev, n, s));
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));  // h_addrs / table_members are pageable
+    c->table_members = c->h_addrs;
+    c->tables_valid = true;
     c->first_cur = 0;
     c->filter_dirty = false;
     return RSB_OK;
@@ -156,8 +163,8 @@ constexpr int kMaxReplayIterations = 16;
 
 // Returns 1 when the batch was replayed on the device (messages in c->d_surv as rsb_message records,
 // counters in cnt), 0 when the host path has to take it, < 0 on error.
-// direct_out (optional): the caller's record buffer.  The message list is then emitted in parts and every finished part is
-// copied out on the copy stream beside the emit kernel of the next one (*direct = 1; the caller waits for c->copy_stream).
+// direct_out (optional): the caller's record buffer.  If the device can address it (pinned host memory), the emit kernel
+// writes the records there itself (*direct = 1) and no device -> host copy follows.
 int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint32_t cnt[kCntCount], rsb_message *direct_out = nullptr,
                   size_t direct_cap = 0, int *direct = nullptr) {
     const BatchArgs &a = b.pending_args;
@@ -185,17 +192,44 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
     r.t_cur = c->d_first_add[c->first_cur];  // seeded with the optimistic "first added at" entries (k_replay_seed)
     r.t_next = c->d_first_add[c->first_cur ^ 1];
     HIP_TRY(c, launch_replay_bounds(r, s));
-    bool converged = false;
+    // Records straight into the caller's buffer when that is pinned host memory the device can address (hipHostMalloc /
+    // hipHostRegister, e.g. torch's pin_memory): the emit kernel's stores then are the device -> host transfer.
+    bool to_host = false;
+    r.host_out = nullptr;
+    if (direct_out && direct && direct_cap) {
+        const uint32_t hcap = (uint32_t)(direct_cap < 0xffffffffull ? direct_cap : 0xffffffffull);
+        hipPointerAttribute_t lo_attr, hi_attr;
+        const bool lo_ok = hipPointerGetAttributes(&lo_attr, direct_out) == hipSuccess && lo_attr.type == hipMemoryTypeHost && lo_attr.devicePointer;
+        const bool hi_ok = lo_ok && hipPointerGetAttributes(&hi_attr, (const char *)(direct_out + hcap) - 1) == hipSuccess &&
+                           hi_attr.type == hipMemoryTypeHost && hi_attr.devicePointer;
+        if (!lo_ok || !hi_ok) (void)hipGetLastError();  // pageable memory: not an error, the copy path takes it
+        if (hi_ok && (const char *)hi_attr.devicePointer - (const char *)lo_attr.devicePointer == (ptrdiff_t)((size_t)hcap * sizeof(rsb_message) - 1)) {
+            r.host_out = (rsb_message *)lo_attr.devicePointer;
+            r.host_cap = hcap;
+            to_host = true;
+        }
+    }
+    // The first round is followed at once by the list and the records (the optimistic start is nearly always the fixed
+    // point): one wait for "did the table move" and the counters together.  If it did move, those records are discarded,
+    // the iteration goes on and they are written again.
+    bool converged = false, emitted = false;
     for (int it = 0; it < kMaxReplayIterations && !converged; ++it) {
         r.t_cur = c->d_first_add[c->first_cur];
         r.t_next = c->d_first_add[c->first_cur ^ 1];
         HIP_TRY(c, launch_replay_iteration(a, r, s));
         uint32_t changed = 0;
         HIP_TRY(c, hipMemcpyAsync(&changed, b.d_counters + kCntChanged, sizeof(changed), hipMemcpyDeviceToHost, s));
+        if (it == 0) {
+            HIP_TRY(c, launch_replay_select(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
+            HIP_TRY(c, launch_replay_emit(a, r, s));
+            HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(c->h_blk_counts.data(), c->d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        }
         HIP_TRY(c, hipStreamSynchronize(s));
         ++c->timing.replay_iterations;
         if (!changed) {
             converged = true;
+            emitted = it == 0;
         } else {
             // the table this walk produced becomes the current one; the other goes back to "before this batch"
             c->first_cur ^= 1;
@@ -204,42 +238,24 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
     }
     if (!converged) {
         c->filter_dirty = true;
+        c->tables_valid = false;  // an iteration's intermediate values are in them
         return 0;
     }
-    HIP_TRY(c, launch_replay_select(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
-    bool parts_out = false;
-    if (direct_out && direct) {
-        uint32_t nacc = 0;
-        HIP_TRY(c, hipMemcpyAsync(&nacc, b.d_counters + kCntAccepted, sizeof(nacc), hipMemcpyDeviceToHost, s));
+    if (!emitted) {
+        HIP_TRY(c, launch_replay_select(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
+        HIP_TRY(c, launch_replay_emit(a, r, s));
+        HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(c->h_blk_counts.data(), c->d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
-        if (nacc > 0 && nacc <= r.out_cap && nacc <= direct_cap) {
-            const uint32_t chunk = ((nacc + rsb_ctx::kEmitParts - 1) / rsb_ctx::kEmitParts + 63u) & ~63u;
-            int p = 0;
-            for (uint32_t lo = 0; lo < nacc; lo += chunk, ++p) {
-                ReplayArgs part = r;
-                part.emit_lo = lo;
-                part.emit_hi = lo + chunk < nacc ? lo + chunk : nacc;
-                HIP_TRY(c, launch_replay_emit(a, part, s));
-                HIP_TRY(c, hipEventRecord(c->ev_part[p], s));
-                HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_part[p], 0));
-                HIP_TRY(c, hipMemcpyAsync(direct_out + lo, r.out + lo, (size_t)(part.emit_hi - lo) * sizeof(rsb_message), hipMemcpyDeviceToHost, c->copy_stream));
-            }
-            parts_out = true;
-        }
     }
-    if (!parts_out) {
-        ReplayArgs all = r;
-        all.emit_lo = all.emit_hi = 0;
-        HIP_TRY(c, launch_replay_emit(a, all, s));
-    }
-    HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(c->h_blk_counts.data(), c->d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, launch_replay_fold(r, s));  // the batch's new members become "in the filter before the next batch" (asynchronous)
+    const bool parts_out = to_host && cnt[kCntAccepted] <= r.host_cap && cnt[kCntAccepted] <= r.out_cap;
     // The tables answer "is this address in the filter" as a set.  The reference's open-addressing table does
     // the same until it is full (icao_filter.c:76-79, 101-106): stay well clear of that, else replay on the host.
     const uint32_t nnew = cnt[kCntNewAdders];
     if (nnew > rsb_ctx::kNewAddersCap || c->replay.filter().active_slots_used() + 2 * (uint64_t)nnew + 1 >= IcaoFilter::kSlots) {
         c->filter_dirty = true;
+        c->tables_valid = false;  // entries folded to 0 that the host does not know of
         return 0;
     }
     if (direct) *direct = parts_out ? 1 : 0;
@@ -247,7 +263,10 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
         c->h_new_adders.resize(nnew);
         HIP_TRY(c, hipMemcpy(c->h_new_adders.data(), c->d_new_adders, nnew * sizeof(uint2), hipMemcpyDeviceToHost));
         std::sort(c->h_new_adders.begin(), c->h_new_adders.end(), [](const uint2 &x, const uint2 &y) { return x.x < y.x; });
-        for (const uint2 &e : c->h_new_adders) c->replay.filter().add(e.y);  // in the order the reference learns them
+        for (const uint2 &e : c->h_new_adders) {
+            c->replay.filter().add(e.y);  // in the order the reference learns them
+            c->table_members.push_back(e.y);  // k_replay_fold has set its entries to 0
+        }
     }
     return 1;
 }
@@ -299,9 +318,6 @@ void rsb_destroy(rsb_ctx *c) {
             if (ev) (void)hipEventDestroy(ev);
     }
     if (c->replay_stream) (void)hipStreamDestroy(c->replay_stream);
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    for (hipEvent_t ev : c->ev_part)
-        if (ev) (void)hipEventDestroy(ev);
     for (void *p : c->d_carry)
         if (p) (void)hipFree(p);
     for (void *p : ptrs)
@@ -653,10 +669,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         const bool parts_ok = !wire && out && cnt[kCntAc] == 0;
         on_device = device_replay(c, b, n_items, s, cnt, parts_ok ? out : nullptr, cap, &direct_parts);
         if (on_device < 0) return on_device;
-        if (!on_device) {
-            HIP_TRY(c, hipStreamSynchronize(c->copy_stream));  // parts already under way: the host path rewrites the buffer afterwards
-            direct_parts = 0;
-        }
+        if (!on_device) direct_parts = 0;  // (whatever the kernel wrote to the buffer, the host path rewrites it)
     }
     uint32_t nsurv = 0;
     if (!on_device) {
@@ -679,6 +692,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         c->err = buf;
         c->finished = true;
         c->filter_dirty = true;
+        c->tables_valid = false;
         return RSB_EOVERFLOW;
     }
 
@@ -701,9 +715,8 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
             on_dev_list = rc == 1;
         }
         if (direct_parts) {
-            // the parts are on their way (or there): wait for the last one
+            // the emit kernel wrote the records into the caller's buffer itself
             n = nlist;
-            HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
             delivered = true;
         } else if (on_dev_list && wire) {
             // encode where the records are, only the wire bytes cross PCIe

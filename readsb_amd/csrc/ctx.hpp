@@ -66,6 +66,11 @@ struct rsb_ctx {
     uint32_t *d_first_add[2] = {nullptr, nullptr};  // 2 x 2^24 "first added at" tables (kernels.hpp ReplayArgs)
     int first_cur = 0;
     bool filter_dirty = true;       // the tables do not mirror replay.filter() (reset, external add / expire, host replay)
+    // tables_valid: both tables are "never" everywhere except the entries listed in table_members (and address 0), which are 0.
+    // A mirror then only undoes / sets those entries instead of refilling 2 x 64 MB.  False after anything that left an
+    // iteration's intermediate values in them.
+    bool tables_valid = false;
+    std::vector<uint32_t> table_members;
     bool host_replay_only = false;  // RSB_FLAG_HOST_REPLAY
     bool defer_prune = false;       // RSB_FLAG_DEFER_PRUNE: k_prune runs at collect time
     bool exact_stats = false;       // RSB_FLAG_EXACT_STATS: every gated offset goes to the host replay, block means are kept
@@ -105,9 +110,6 @@ struct rsb_ctx {
     bool any_pending() const { return submitted != collected; }
     uint64_t last_n = 0;              // samples of the last collected batch
     hipStream_t replay_stream = nullptr;  // sort / replay / copy-out run here, behind the batch's scan (event) and beside the next one's
-    hipStream_t copy_stream = nullptr;    // device -> host copies of finished parts of the message list, beside the emit kernel of the next part
-    static constexpr int kEmitParts = 4;
-    hipEvent_t ev_part[kEmitParts] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t stream_pos = 0;          // of the next batch to collect
     uint64_t submit_pos = 0;          // of the next batch to submit
     bool finished = false, submit_finished = false;

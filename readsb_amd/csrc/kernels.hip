@@ -1244,13 +1244,15 @@ struct __attribute__((aligned(16))) EmitShared {
     uint16_t lut[16384];
     uint32_t coef[10][16];
     uint32_t gsyn[(12 + 24) * 32];  // + one zero row: the 24th step
+    uint32_t rec[kEmitWaves][64 * 14];  // per wavefront: its 64 records, so that they leave as contiguous 16-byte stores
 };
 
 typedef uint4 __attribute__((aligned(4))) uint4_a4;
 
 template <int FMT>
 __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs a, const ReplayArgs r) {
-    __shared__ EmitShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char emit_lds[];  // 66 KB: over the static limit
+    EmitShared &sh = *reinterpret_cast<EmitShared *>(emit_lds);
     constexpr uint32_t kT = 64 * kEmitWaves;
     if (FMT == kFmtUC8)
         for (uint32_t i = threadIdx.x; i < 16384; i += kT) {  // the scan kernel's folded table (uc8_addr)
@@ -1275,13 +1277,12 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
     const uint32_t lane = threadIdx.x & 63;
     uint32_t nacc = a.counters[kCntAccepted];
     if (nacc > r.out_cap) nacc = r.out_cap;
-    const uint32_t first = r.emit_hi ? r.emit_lo : 0u;  // a multiple of 64
-    if (r.emit_hi && r.emit_hi < nacc) nacc = r.emit_hi;
+    if (r.host_out && nacc > r.host_cap) nacc = r.host_cap;
     uint32_t by_errors[3] = {0, 0, 0};  // wave-uniform
     constexpr int kRawVecs = (FMT == kFmtUC8 || FMT == kFmtMag16) ? 1 : 2;
     constexpr int kBps = 2 * kRawVecs;
     const uint32_t nthreads = gridDim.x * kT;
-    for (uint32_t base = first + ((blockIdx.x * kT + threadIdx.x) & ~63u); base < nacc; base += nthreads) {
+    for (uint32_t base = (blockIdx.x * kT + threadIdx.x) & ~63u; base < nacc; base += nthreads) {
         const uint32_t mi = base + lane;
         const bool valid = mi < nacc;
         uint32_t g = 0, phase = 0, info = kComboDf17 << 27, score = 0;
@@ -1417,7 +1418,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
             const bool df11 = combo >= kComboDf11Iid0 && combo <= kComboDf11IidX + 1;
             const double signal_power = (double)pw / 65535.0 / 65535.0;
             const double level = signal_power / (double)signal_len;
-            uint32_t *o = (uint32_t *)&r.out[mi];  // rsb_message, packed: 14 dwords
+            uint32_t *o = &sh.rec[threadIdx.x >> 6][lane * 14];  // rsb_message, packed: 14 dwords
             o[0] = (uint32_t)ts;
             o[1] = (uint32_t)(ts >> 32);
             o[2] = __builtin_bswap32(w[0]);  // msg[0..3]
@@ -1433,6 +1434,25 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
             const uint64_t lv = __builtin_bit_cast(uint64_t, level);
             o[12] = (uint32_t)lv;
             o[13] = (uint32_t)(lv >> 32);
+        }
+        {
+            // The wavefront's records [base, base + nv) are contiguous in the list: 3584 bytes as 224 x 16-byte stores, each
+            // instruction covering 1 KB without holes.  That is what makes writing straight into the caller's pinned host
+            // buffer (r.host_out: no device -> host copy afterwards) run at PCIe rate; dword stores at a 56-byte stride do not.
+            wave_sync();
+            const uint32_t nv = min(64u, nacc - base);
+            rsb_message *dst = (r.host_out ? r.host_out : r.out) + base;
+            const uint32_t *src = sh.rec[threadIdx.x >> 6];
+            if (nv == 64 && ((uintptr_t)dst & 15u) == 0) {
+#pragma unroll
+                for (uint32_t t = 0; t < 4; ++t) {
+                    const uint32_t q = t * 64 + lane;
+                    if (q < 224) ((uint4 *)dst)[q] = ((const uint4 *)src)[q];
+                }
+            } else {
+                for (uint32_t q = lane; q < nv * 14; q += 64) ((uint32_t *)dst)[q] = src[q];
+            }
+            wave_sync();
         }
         by_errors[0] += (uint32_t)__popcll(__ballot(valid && nerr == 0));
         by_errors[1] += (uint32_t)__popcll(__ballot(valid && nerr == 1));
@@ -2183,7 +2203,9 @@ inline unsigned item_grid(uint32_t n) {
 
 hipError_t launch_replay_bounds(const ReplayArgs &r, hipStream_t s) {
     hipLaunchKernelGGL(k_replay_bounds, dim3(item_grid(r.n_items + 1)), dim3(kThreads), 0, s, r);
-    if (r.n_items && r.t_cur) hipLaunchKernelGGL(k_replay_seed, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);
+    // (a small grid: the items are in ascending offset order, so the threads' later rounds find their address already entered
+    // and skip the atomic -- with one thread per item, thousands of atomics queued on each aircraft's entry)
+    if (r.n_items && r.t_cur) hipLaunchKernelGGL(k_replay_seed, dim3(item_grid(r.n_items) > 96 ? 96 : item_grid(r.n_items)), dim3(kThreads), 0, s, r);
     return hipGetLastError();
 }
 
@@ -2206,34 +2228,34 @@ hipError_t launch_replay_select(const BatchArgs &a, const ReplayArgs &r, void *t
     hipError_t e = hipMemsetAsync(&a.counters[kCntAccepted], 0, 5 * sizeof(uint32_t), s);  // accepted, new adders, by errors
     if (e != hipSuccess || r.n_items == 0) return e;
     hipLaunchKernelGGL(k_replay_list, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, a.counters);
-    hipLaunchKernelGGL(k_replay_fold, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return hipcub::DeviceSelect::Flagged(temp, temp_bytes, hipcub::CountingInputIterator<uint32_t>(0), r.acc, r.acc_idx, &a.counters[kCntAccepted],
                                          (int)r.n_items, s);
 }
 
+hipError_t launch_replay_fold(const ReplayArgs &r, hipStream_t s) {
+    if (r.n_items) hipLaunchKernelGGL(k_replay_fold, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);
+    return hipGetLastError();
+}
+
 hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream_t s) {
     if (r.n_items == 0) return hipSuccess;
-    // a part of the list gets a part of the grid (every workgroup first builds its 40 KB of LDS tables)
-    const uint32_t span = r.emit_hi ? r.emit_hi - r.emit_lo : 0xffffffffu;
-    unsigned grid = 512;
-    if (span != 0xffffffffu) {
-        grid = (span + 64 * kEmitWaves * 4 - 1) / (64 * kEmitWaves * 4);
-        grid = grid < 1 ? 1 : (grid > 512 ? 512 : grid);
-    }
     return by_format(a.fmt, [&](auto F) {
-        hipLaunchKernelGGL(k_replay_emit<decltype(F)::value>, dim3(grid), dim3(64 * kEmitWaves), 0, s, a, r);
+        auto kern = k_replay_emit<decltype(F)::value>;
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmitShared));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(512), dim3(64 * kEmitWaves), sizeof(EmitShared), s, a, r);
         return hipGetLastError();
     });
 }
 
 hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s) {
-    const hipError_t e = launch_replay_select(a, r, temp, temp_bytes, s);
+    hipError_t e = launch_replay_select(a, r, temp, temp_bytes, s);
     if (e != hipSuccess) return e;
-    ReplayArgs all = r;
-    all.emit_lo = all.emit_hi = 0;
-    return launch_replay_emit(a, all, s);
+    e = launch_replay_fold(r, s);
+    if (e != hipSuccess) return e;
+    return launch_replay_emit(a, r, s);
 }
 
 // ---- Mode A/C merge: one thread per dword of a 56-byte record
@@ -2308,6 +2330,17 @@ hipError_t launch_wire_offsets(const WireArgs &w, void *temp, size_t temp_bytes,
 hipError_t launch_wire_write(const WireArgs &w, hipStream_t s) {
     if (w.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_wire_write, dim3((w.n + kThreads - 1) / kThreads), dim3(kThreads), 0, s, w);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(kThreads) void k_filter_clear(uint32_t *t0, uint32_t *t1, const uint32_t *addrs, uint32_t n) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) t0[addrs[i]] = t1[addrs[i]] = kNever;
+}
+
+hipError_t launch_filter_update(uint32_t *t0, uint32_t *t1, const uint32_t *stale_dev, uint32_t n_stale, const uint32_t *addrs_dev, uint32_t n, hipStream_t s) {
+    if (n_stale) hipLaunchKernelGGL(k_filter_clear, dim3((n_stale + kThreads - 1) / kThreads), dim3(kThreads), 0, s, t0, t1, stale_dev, n_stale);
+    hipLaunchKernelGGL(k_filter_fill, dim3((n + kThreads) / kThreads), dim3(kThreads), 0, s, t0, t1, addrs_dev, n);  // (also sets entry 0)
     return hipGetLastError();
 }
 

@@ -109,7 +109,8 @@ struct ReplayArgs {
     rsb_message *out;
     uint32_t out_cap;
     uint64_t g0;             // stream position of the batch
-    uint32_t emit_lo, emit_hi;  // k_replay_emit: the range of accepted messages this launch writes (emit_hi = 0: all of them)
+    rsb_message *host_out;   // k_replay_emit: if set, the records go here (the caller's pinned host buffer, device-mapped) instead of `out`
+    uint32_t host_cap;       // ... which holds this many
 };
 constexpr uint32_t kNever = 0xffffffffu;
 
@@ -127,10 +128,12 @@ hipError_t launch_replay_bounds(const ReplayArgs &r, hipStream_t s);  // once pe
 hipError_t launch_replay_iteration(const BatchArgs &a, const ReplayArgs &r, hipStream_t s);
 hipError_t launch_replay_reset(const BatchArgs &a, const ReplayArgs &r, uint32_t *table, hipStream_t s);
 hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s);
-// the two halves of launch_replay_finish on their own: the list of accepted items (count -> counters[kCntAccepted]), and the
-// records of the messages [r.emit_lo, r.emit_hi) of that list (so that a caller can copy finished ranges out meanwhile)
+// the two halves of launch_replay_finish on their own: the list of accepted items (count -> counters[kCntAccepted]), and
+// their records (to r.out, or straight to r.host_out)
 hipError_t launch_replay_select(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s);
 hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream_t s);
+// (launch_replay_select leaves the tables alone; this folds the batch's new members into them once the fixed point is certain)
+hipError_t launch_replay_fold(const ReplayArgs &r, hipStream_t s);
 // wire formats (wire.hpp) of n message records on the device: launch_wire_offsets leaves the byte offset of message i in
 // off[i] and the total in off[n]; launch_wire_write stores the bytes at out + off[i]
 struct WireArgs {
@@ -160,6 +163,8 @@ hipError_t launch_wire_offsets(const WireArgs &w, void *temp, size_t temp_bytes,
 hipError_t launch_wire_write(const WireArgs &w, hipStream_t s);
 // first-add tables := "never" everywhere, 0 for address 0 and the n given addresses
 hipError_t launch_filter_rebuild(uint32_t *t0, uint32_t *t1, const uint32_t *addrs_dev, uint32_t n, hipStream_t s);
+// the same without refilling the tables: stale_dev[0..n_stale) are the entries that are 0 now and go back to "never" first
+hipError_t launch_filter_update(uint32_t *t0, uint32_t *t1, const uint32_t *stale_dev, uint32_t n_stale, const uint32_t *addrs_dev, uint32_t n, hipStream_t s);
 hipError_t launch_modeac(const BatchArgs &a, hipStream_t s);
 // integer formats: sum(mag), sum(mag^2) per 131072-sample block into a.block_sums (zeroed by the caller); launch_modeac
 // runs it itself when it is given no block means

@@ -323,3 +323,29 @@ def test_one_recording_in_shards(nranks, seg_blocks, built):
         alone.append(rd.shard_finish(ch, adders, None, 1 << 20)[0])
         ch.close()
     assert sum(m.size for m in alone) < want.size
+
+
+def test_records_written_straight_to_pinned_buffer(built):
+    """rsb_collect into pinned host memory (what bench.py passes): the emit kernel then writes the records there itself, no
+    device -> host copy.  Same list as into pageable memory and as the reference's; several batches, the last one ragged, and
+    a buffer offset that is only 8-byte aligned (the unaligned store path)."""
+    import torch
+
+    name = "mixed_fix1"
+    sc, kw = SCENARIOS[name]
+    iq = generate(sc)
+    gold, _, _ = load_demod(name)
+    dev_iq = torch.from_numpy(iq).cuda()
+    pinned = torch.empty((gold.size + 64) * 56, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE)
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], max_batch_samples=4 * 131072)
+    pos, start = 1, 0  # record 1: 56 bytes into the buffer
+    while True:
+        n = min(4 * 131072, sc.n_samples - start)
+        ch.submit(dev_iq.data_ptr() + 2 * start, n)
+        pos += ch.collect(out=pinned[pos:]).size
+        assert ch.timing()["replay_on_device"] == 1
+        start += n
+        if n < 4 * 131072:
+            break
+    ch.close()
+    assert first_mismatch(gold, pinned[1:pos].view(REC_DTYPE)) is None
