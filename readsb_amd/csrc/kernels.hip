@@ -903,7 +903,12 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 T += 128;
                 return b;
             };
-            for (int u = 0; u < 11; ++u) {  // bits 0..54
+            {  // bits 0..54: group 0, then five pairs (the window registers rotate with period two: no copies)
+                const uint32_t b = group(true, 31u);
+                lo = b;
+            }
+#pragma unroll 2
+            for (int u = 1; u < 11; ++u) {
                 const uint32_t b = group(true, 31u);
                 hi = __builtin_amdgcn_alignbit(hi, lo, 27);
                 lo = (lo << 5) | b;
