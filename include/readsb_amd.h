@@ -199,6 +199,32 @@ int rsb_process_host(rsb_ctx *ctx, const void *iq_host, uint64_t nsamples,
  * power of each of its 131072-sample blocks.  For checking the demodulators apart from the converter's tolerance. */
 int rsb_get_batch_magnitudes(rsb_ctx *ctx, uint16_t *mag_host, uint64_t nsamples, double *block_means);
 
+/* ---- live sources: the producer half of the mag_buf ring ---------------------- */
+
+/* A live SDR handler hands over one block of raw IQ at a time: plutosdrCallback (sdr_plutosdr.c:168-244) and
+ * ifileRun (sdr_ifile.c:176-253) fill one mag_buf of 131072 samples per call, copy the previous buffer's last 326
+ * magnitudes in front of it -- or zeros when samples were dropped in between (sdr_plutosdr.c:224-228) -- stamp it with
+ * sampleCounter * 12e6 / sample_rate and signal the demodulator thread (readsb.c:847-911).  rsb_stream is that hand-over
+ * for the GPU consumer: blocks are staged in pinned host memory, every blocks_per_batch of them go to the device as one
+ * batch (host -> device copy and scan of batch k run while the caller fills batch k + 1, two batches in flight), and
+ * the messages of every finished batch reach `sink` in stream order, exactly those rsb_process_host returns for the
+ * same samples.  Latency bound: blocks_per_batch x 54.6 ms of samples (at 2.4 MS/s) + one batch's processing;
+ * rsb_stream_flush submits what is staged and delivers everything outstanding (a timer's job).
+ *   nsamples        131072, or fewer for the last block of the stream (as rsb_submit)
+ *   dropped_before  samples the source lost between the previous block and this one (mag_buf.dropped), whole blocks
+ *                   only: the staged blocks are flushed, the stream position moves on by that many samples (timestamps
+ *                   jump as sampleCounter does, sdr_plutosdr.c:208-213) and this block starts from a zero carry.
+ *                   The ICAO filter is kept.  Not available with dc_filter (rsb_seek).
+ * The context must have max_batch_samples >= blocks_per_batch * 131072 and nothing pending; while the stream is open
+ * the caller does not call rsb_submit / rsb_collect on it.  sink runs on the caller's thread, inside push / flush /
+ * close; the records it is given are valid during the call only. */
+typedef struct rsb_stream rsb_stream;
+typedef void (*rsb_stream_sink)(void *user, const rsb_message *msgs, size_t n);
+int rsb_stream_open(rsb_ctx *ctx, uint32_t blocks_per_batch, rsb_stream_sink sink, void *user, rsb_stream **out);
+int rsb_stream_push(rsb_stream *st, const void *iq_host, uint32_t nsamples, uint64_t dropped_before);
+int rsb_stream_flush(rsb_stream *st);
+int rsb_stream_close(rsb_stream *st);   /* flush, then free the stream (not the context) */
+
 /* ---- wire formats of the message list ---------------------------------------- */
 
 /* What modesQueueOutput (net_io.c:1249-1276) writes for Beast-binary clients (modesSendBeastOutput, :760-826:

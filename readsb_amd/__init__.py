@@ -89,6 +89,10 @@ SYMBOLS = {
     "rsb_forwarder_create": (_VP, []),
     "rsb_forwarder_destroy": (None, [_VP]),
     "rsb_forwarder_push": (C.c_int, [_VP, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
+    "rsb_stream_open": (C.c_int, [_VP, C.c_uint32, _VP, _VP, C.POINTER(_VP)]),
+    "rsb_stream_push": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint64]),
+    "rsb_stream_flush": (C.c_int, [_VP]),
+    "rsb_stream_close": (C.c_int, [_VP]),
     "rsb_host_replay": (C.c_int, [C.c_int, C.c_uint64, _VP, _SZ, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
 }
 
@@ -113,6 +117,40 @@ def lib():
 
 class RsbError(RuntimeError):
     pass
+
+
+STREAM_SINK = C.CFUNCTYPE(None, _VP, _VP, _SZ)
+
+
+class Stream:
+    """rsb_stream over a Channel: blocks of a live source in, messages out (collected in .messages())."""
+
+    def __init__(self, ch: "Channel", blocks_per_batch: int):
+        self.ch, self.l = ch, ch.l
+        self.parts = []
+
+        def sink(_user, msgs, n):
+            self.parts.append(np.ctypeslib.as_array(C.cast(msgs, C.POINTER(C.c_uint8)), shape=(n * MSG_DTYPE.itemsize,)).view(MSG_DTYPE).copy())
+
+        self._sink = STREAM_SINK(sink)  # kept alive as long as the stream
+        h = _VP()
+        ch._check(self.l.rsb_stream_open(ch.h, blocks_per_batch, C.cast(self._sink, _VP), None, C.byref(h)), "rsb_stream_open")
+        self.h = h
+
+    def push(self, block: np.ndarray, dropped_before: int = 0):
+        raw = np.ascontiguousarray(block).view(np.uint8).reshape(-1)
+        self.ch._check(self.l.rsb_stream_push(self.h, raw.ctypes.data if raw.size else None, raw.size // self.ch.bps, dropped_before), "rsb_stream_push")
+
+    def flush(self):
+        self.ch._check(self.l.rsb_stream_flush(self.h), "rsb_stream_flush")
+
+    def close(self):
+        if self.h:
+            h, self.h = self.h, None
+            self.ch._check(self.l.rsb_stream_close(h), "rsb_stream_close")
+
+    def messages(self) -> np.ndarray:
+        return np.concatenate(self.parts) if self.parts else np.zeros(0, dtype=MSG_DTYPE)
 
 
 class Channel:
