@@ -123,3 +123,12 @@ def test_no_silent_cpu_fallback():
     assert l.rsb_create(C.byref(cfg), C.byref(h)) == -2 and not h.value  # RSB_ENODEV
     with pytest.raises(readsb_amd.RsbError):
         readsb_amd.Channel()
+
+
+def test_stream_entry_points_reject_bad_arguments_without_a_device():
+    l = readsb_amd.lib()
+    h = C.c_void_p()
+    assert l.rsb_stream_open(None, 4, None, None, C.byref(h)) == -1 and not h.value
+    assert l.rsb_stream_push(None, None, 0, 0) == -1
+    assert l.rsb_stream_flush(None) == -1
+    assert l.rsb_stream_close(None) == -1
