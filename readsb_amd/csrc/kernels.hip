@@ -958,7 +958,6 @@ __global__ __launch_bounds__(kThreads) void k_prune(const BatchArgs a) {
         if (threadIdx.x == 0) atomicAdd(&a.counters[kCntOverflow], 1u);
         n = cap;
     }
-    if (threadIdx.x == 0 && n) atomicAdd(&a.counters[kCntItemsTotal], n);
     const ItemRec *items = a.items + (size_t)r * a.item_region;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     auto keeps = [&](const ItemRec &rec) {
@@ -983,7 +982,9 @@ __global__ __launch_bounds__(kThreads) void k_prune(const BatchArgs a) {
     if (threadIdx.x == 0) {
         uint32_t total = 0;
         for (uint32_t w = 0; w < kThreads / 64; ++w) total += wave_count[w];
-        block_base = total ? atomicAdd(&a.counters[kCntSurvItems], total) : 0u;
+        // kept items (the reservation) and all items (a statistic) in one atomic: same-address atomics are what this kernel waits for
+        static_assert(kCntSurvItems % 2 == 0 && kCntItemsTotal == kCntSurvItems + 1, "the two counters form one aligned 64-bit word");
+        block_base = n ? (uint32_t)atomicAdd((unsigned long long *)&a.counters[kCntSurvItems], (unsigned long long)total | ((unsigned long long)n << 32)) : 0u;
     }
     __syncthreads();
     uint32_t slot0 = block_base;

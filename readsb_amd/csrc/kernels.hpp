@@ -27,13 +27,13 @@ constexpr int kScanWavesPerGroup = RSB_SCAN_WAVES;
 // device counters (one uint32 each)
 enum : int {
     kCntItems = 0,     // item records appended by the scan kernel
-    kCntSurvItems,     // items kept by the prune kernel
     kCntAc,            // Mode A/C candidates
+    kCntSurvItems,     // items kept by the prune kernel   } one 8-byte pair: k_prune bumps both with a single
+    kCntItemsTotal,    // all items (sum over regions)     } 64-bit atomic per workgroup
     kCntGated,         // offsets that passed the preamble gate
     kCntSurvivors,     // distinct offsets among the kept items (written by the unique step)
     kCntSlowPath,      // candidates / items that overflowed an LDS queue and took the per-thread path
     kCntOverflow,      // item regions that overflowed (results incomplete -> RSB_EOVERFLOW)
-    kCntItemsTotal,    // all items (sum over regions), for statistics
     kCntChanged,       // device replay: the first-add table moved in this iteration
     kCntAccepted,      // device replay: messages accepted
     kCntNewAdders,     // device replay: addresses the filter learned in this batch
