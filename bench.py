@@ -103,6 +103,30 @@ def cpu_baseline_sharded(seg: np.ndarray, single: dict, budget_s: float = 6.0, f
             "sample": f"{cores} processes at once (one channel per core), each {reps} passes over the {n}-sample segment; wall time incl. process start"}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without torchrun: N fresh child processes, one rank per GPU, rendezvous on 127.0.0.1.
+    The parent never initialises the GPU (torch.cuda.device_count() does not) and only relays rank 0's JSON line."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} HIP device(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,7 +146,13 @@ def main() -> int:
     ap.add_argument("--modeac", action="store_true", help="configs[4]: also demodulate2400AC")
     ap.add_argument("--fix-bits", type=int, default=1, choices=(0, 1, 2), help="0 --no-fix, 1 --fix (default), 2 --aggressive (configs[4])")
     ap.add_argument("--dense", action="store_true", help="configs[4] traffic: dense, low SNR, 1- and 2-bit errors, Mode A/C replies")
+    ap.add_argument("--channels-per-gpu", type=int, default=1,
+                    help="configs[3]: split each GPU's --samples over this many independent receiver channels (own filter, own stream position), "
+                         "all submitted before the first is collected")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)  # no launcher around us: start one rank per GPU ourselves (nothing has touched the GPU yet)
 
     import torch
     import torch.distributed as dist

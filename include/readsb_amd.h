@@ -58,7 +58,9 @@ typedef struct rsb_config {
     uint32_t queue_div;        /* device queues hold max_batch_samples/queue_div candidates (0 -> 32) */
     uint64_t max_batch_samples;/* largest nsamples a single rsb_submit will be given */
     uint32_t flags;            /* RSB_FLAG_* */
-    uint32_t reserved;
+    uint32_t scan_workgroups;  /* workgroups (= CUs) the scan kernel's persistent grid may take; 0 = one per CU of the device.
+                                  Fewer leave CUs to the replay kernels of the previous batch (two batches in flight), and a
+                                  very small number makes every wavefront walk many strips of a small input (tests) */
 } rsb_config;
 
 /* Run the sequential half (best phase, decode, greedy skip, filter updates) on the host from the

@@ -34,7 +34,7 @@ assert MSG_DTYPE.itemsize == 56 and CAND_DTYPE.itemsize == 96 and AC_DTYPE.items
 class Config(C.Structure):
     _fields_ = [("input_format", C.c_int32), ("dc_filter", C.c_int32), ("fix_bits", C.c_int32), ("mode_ac", C.c_int32),
                 ("device", C.c_int32), ("queue_div", C.c_uint32), ("max_batch_samples", C.c_uint64),
-                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+                ("flags", C.c_uint32), ("scan_workgroups", C.c_uint32)]
 
 
 FLAG_HOST_REPLAY = 1
@@ -157,12 +157,12 @@ class Channel:
     """One receiver channel (rsb_ctx)."""
 
     def __init__(self, fmt="UC8", fix_bits=1, mode_ac=False, dc_filter=False, device=0, max_batch_samples=1 << 24, queue_div=0,
-                 host_replay=False, exact_stats=False, defer_prune=False):
+                 host_replay=False, exact_stats=False, defer_prune=False, scan_workgroups=0):
         self.l = lib()
         self.fmt = fmt
         self.bps = 2 if fmt == "UC8" else 4
         cfg = Config(FORMATS[fmt], int(dc_filter), int(fix_bits), int(mode_ac), int(device), int(queue_div), int(max_batch_samples),
-                     (FLAG_HOST_REPLAY if host_replay else 0) | (FLAG_EXACT_STATS if exact_stats else 0) | (FLAG_DEFER_PRUNE if defer_prune else 0), 0)
+                     (FLAG_HOST_REPLAY if host_replay else 0) | (FLAG_EXACT_STATS if exact_stats else 0) | (FLAG_DEFER_PRUNE if defer_prune else 0), int(scan_workgroups))
         h = _VP()
         rc = self.l.rsb_create(C.byref(cfg), C.byref(h))
         if rc != 0:

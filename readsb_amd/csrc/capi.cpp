@@ -83,6 +83,8 @@ int setup_device(rsb_ctx *c) {
     if (const char *e = std::getenv("RSB_STAGE_LIMIT")) c->stage_limit = std::atoi(e);  // ablation timing only
     if (const char *e = std::getenv("RSB_ABL")) c->debug_flags = std::atoi(e);
     if (const char *e = std::getenv("RSB_SCAN_GRID")) c->scan_grid = std::atoi(e);
+    if (c->cfg.scan_workgroups && (int)c->cfg.scan_workgroups < c->scan_grid) c->scan_grid = (int)c->cfg.scan_workgroups;
+    if (c->scan_grid < 1) c->scan_grid = 1;
     // --dcfilter keeps one magnitude buffer, which the replay of a batch still reads: one batch in flight there
     c->nslots = c->cfg.dc_filter ? 1 : 2;
     for (int k = 0; k < c->nslots; ++k) {

@@ -349,3 +349,68 @@ def test_records_written_straight_to_pinned_buffer(built):
             break
     ch.close()
     assert first_mismatch(gold, pinned[1:pos].view(REC_DTYPE)) is None
+
+
+@REPLAY
+@pytest.mark.parametrize("name", ["mixed_fix1", "dense_fix2_ac", "sc16", "exact_2_blocks"])
+def test_persistent_scan_loop_matches_oracle(name, host_replay, built):
+    """The path the benchmark runs: with a grid of two workgroups every wavefront of k_scan walks MANY strips (strip +=
+    strip_step, the register hand-over of the raw-IQ prefetch, item counts carried across strips) -- 2 x 16 wavefronts x 2768
+    offsets per round, i.e. ~23 rounds on a 2 M-sample recording.  Against the oracle and the reference's own lists."""
+    sc, kw = SCENARIOS[name]
+    iq = generate(sc)
+    want, wst = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
+    gold, _, _ = load_demod(name)
+    assert first_mismatch(gold, want) is None
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=1 << 23, host_replay=host_replay,
+                            scan_workgroups=2)
+    got = ch.process_host(iq)
+    assert first_mismatch(want, got.view(REC_DTYPE)) is None
+    assert ch.stats()["demod_accepted"] == [wst["accepted0"], wst["accepted1"], wst["accepted2"]]
+    # and one workgroup, fed in ragged batches: strips that straddle the carry and the end of a batch in every round
+    ch1 = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=3 * 131072, host_replay=host_replay,
+                             scan_workgroups=1)
+    got1 = ch1.process_stream_host(iq, 3)
+    assert first_mismatch(want, got1.view(REC_DTYPE)) is None
+    ch.close()
+    ch1.close()
+
+
+def _long_recording(chunks, chunk_samples, fmt="UC8", **kw):
+    """non-repeating IQ: every chunk from its own seed"""
+    from readsb_amd.synth import Scenario
+
+    return np.concatenate([generate(Scenario(chunk_samples, seed=1000 + 17 * k, fmt=fmt, **kw)) for k in range(chunks)])
+
+
+def test_long_recording_full_grid_matches_oracle(built):
+    """40 Mi samples of non-repeating UC8 IQ in ONE batch on the full grid: beyond 256 workgroups x 16 wavefronts x 2768 =
+    11.3 M samples every wavefront takes a second, third and fourth strip, which is how the 1-Gsample benchmark runs
+    (~95 strips per wavefront).  Bit for bit against the oracle, device and host replay; the device-resident input is what
+    bench.py submits."""
+    import torch
+
+    iq = _long_recording(5, 1 << 23)
+    n = iq.shape[0]
+    want, wst = Oracle(fmt="UC8", nfix=1).run_stream(iq)
+    assert want.size > 20000
+    dev = torch.from_numpy(iq).cuda()
+    for host_replay in (False, True):
+        ch = readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=n, host_replay=host_replay)
+        ch.submit(dev.data_ptr(), n)
+        got = ch.collect(cap=want.size + 1024).copy()
+        assert first_mismatch(want, got.view(REC_DTYPE)) is None
+        assert ch.stats()["demod_accepted"] == [wst["accepted0"], wst["accepted1"], wst["accepted2"]]
+        assert ch.timing()["replay_on_device"] == (0 if host_replay else 1)
+        ch.close()
+
+
+def test_long_recording_dense_aggressive_modeac(built):
+    """BASELINE configs[4] beyond one strip per wavefront: 24 Mi samples of dense low-SNR traffic, --aggressive, Mode A/C."""
+    iq = _long_recording(3, 1 << 23, frames_per_sec=4000, err1_every=7, err2_every=10, modeac_per_sec=300, amp_lo=0.04, amp_hi=0.54)
+    want, wst = Oracle(fmt="UC8", nfix=2, modeac=True).run_stream(iq)
+    ch = readsb_amd.Channel(fmt="UC8", fix_bits=2, mode_ac=True, max_batch_samples=iq.shape[0], queue_div=16)
+    got = ch.process_host(iq, cap=want.size + 1024)
+    assert first_mismatch(want, got.view(REC_DTYPE)) is None
+    assert ch.stats()["demod_modeac"] == wst["modeac"]
+    ch.close()
