@@ -103,6 +103,17 @@ def cpu_baseline_sharded(seg: np.ndarray, single: dict, budget_s: float = 6.0, f
             "sample": f"{cores} processes at once (one channel per core), each {reps} passes over the {n}-sample segment; wall time incl. process start"}
 
 
+def kernel_src_sha() -> str:
+    """identifies the kernel build a committed counter file belongs to (the GPU box has no .git)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "kernels.hpp"):
+        with open(os.path.join(ROOT, "readsb_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without torchrun: N fresh child processes, one rank per GPU, rendezvous on 127.0.0.1.
     The parent never initialises the GPU (torch.cuda.device_count() does not) and only relays rank 0's JSON line."""
@@ -181,12 +192,19 @@ def main() -> int:
     del seg_dev
     torch.cuda.synchronize()
 
+    # channels: the GPU's samples split over C independent receiver channels (configs[3]); every channel = whole copies of the segment
+    C = max(1, args.channels_per_gpu)
+    if C > 1 and (reps % C or args.batches > 1 or args.output != "records"):
+        raise SystemExit("--channels-per-gpu: must divide samples / segment, with --batches 1 and --output records")
+    nc = n // C                                 # samples per channel
     # batches: whole numbers of 131072-sample blocks (only the last one may be ragged)
     nb = max(1, args.batches)
-    bs = -(-n // nb) // 131072 * 131072 or n
-    cuts = list(range(0, n, bs)) + [n]
-    ch = readsb_amd.Channel(fmt=args.format, fix_bits=args.fix_bits, mode_ac=args.modeac, dc_filter=args.dcfilter, device=local_rank,
-                            max_batch_samples=max(b - a for a, b in zip(cuts, cuts[1:])), queue_div=16 if args.dense else 32)
+    bs = -(-nc // nb) // 131072 * 131072 or nc
+    cuts = list(range(0, nc, bs)) + [nc]
+    chans = [readsb_amd.Channel(fmt=args.format, fix_bits=args.fix_bits, mode_ac=args.modeac, dc_filter=args.dcfilter, device=local_rank,
+                                max_batch_samples=max(b - a for a, b in zip(cuts, cuts[1:])), queue_div=16 if args.dense else 32)
+             for _ in range(C)]
+    ch = chans[0]
     stream = torch.cuda.current_stream().cuda_stream
     cap = max(1 << 16, n // (256 if args.dense else 512))
     # the caller's result buffer: pinned, so the device -> host copy of the message list runs at link speed
@@ -194,23 +212,24 @@ def main() -> int:
     wirebuf = torch.empty(cap * readsb_amd.WIRE_MAX_BYTES if args.output != "records" else 1, dtype=torch.uint8, pin_memory=True).numpy()
     keys = ("scan_ms", "prune_ms", "modeac_ms", "sort_ms", "device_replay_ms", "copy_ms", "replay_ms", "total_ms", "replay_iterations", "replay_on_device")
     base = iq.data_ptr()
+    chan_msgs = [0, 0]  # [start, end) of channel 0's records in outbuf after a step
 
     def step(tm=None):
-        """One pass over the recording: batch i + 1 is submitted before batch i is collected."""
-        ch.reset()
+        """One pass over the recording: batch i + 1 is submitted before batch i is collected; with several channels every
+        channel's scan is submitted before the first channel is collected."""
         pos = 0
         acc = {k: 0.0 for k in keys}
         acc["replay_on_device"] = 1
 
-        def collect():
+        def collect(c):
             nonlocal pos
             if args.output == "records":
-                m = ch.collect(out=outbuf[pos:])
+                m = c.collect(out=outbuf[pos:])
                 pos += m.size
             else:
-                b, _ = ch.collect_wire(args.output, mlat=True, out=wirebuf[pos:])
+                b, _ = c.collect_wire(args.output, mlat=True, out=wirebuf[pos:])
                 pos += b.size
-            t = ch.timing()
+            t = c.timing()
             for k in keys:
                 if k == "replay_on_device":
                     acc[k] = min(acc[k], t[k])
@@ -219,11 +238,22 @@ def main() -> int:
                 else:
                     acc[k] += t[k]
 
-        for k in range(len(cuts) - 1):
-            ch.submit(base + bps * cuts[k], cuts[k + 1] - cuts[k], stream)
-            if k >= 1:
-                collect()
-        collect()
+        if C == 1:
+            ch.reset()
+            for k in range(len(cuts) - 1):
+                ch.submit(base + bps * cuts[k], cuts[k + 1] - cuts[k], stream)
+                if k >= 1:
+                    collect(ch)
+            collect(ch)
+            chan_msgs[1] = pos
+        else:
+            for i, c in enumerate(chans):
+                c.reset()
+                c.submit(base + bps * nc * i, nc, stream)
+            for i, c in enumerate(chans):
+                collect(c)
+                if i == 0:
+                    chan_msgs[1] = pos
         if tm is not None:
             for k in keys:
                 tm[k].append(acc[k])
@@ -253,18 +283,31 @@ def main() -> int:
         wire_check = "ok" if np.array_equal(readsb_amd.wire_encode(msgs, out_kind, mlat=True), wire_bytes) else "WIRE-MISMATCH"
     nmsgs = sum(rd.gather_counts(int(msgs.size), dev))   # the result-count gather: the only data the ranks exchange
 
-    # full-size check: the recording is `reps` copies of one segment whose length is a multiple of
-    # 131072, so from the second copy on (filter warm, real overlap) every copy must decode to the same
-    # list shifted by seg_n*5 ticks; the first copies are checked against the oracle in tests/.
-    parity = "n/a"
-    if reps >= 4 and seg_n % 131072 == 0 and not args.dcfilter:  # (the DC filter's state keeps settling: its copies are not identical)
+    # Full-size check, outside the timed region.  The recording is `reps` copies of one segment whose length is a multiple of
+    # 131072, so (a) copy 0 (cold filter, zero overlap) must be what the ORACLE decodes from the segment followed by the
+    # start of its next copy, record for record, and (b) from the second copy on (filter warm, real overlap) EVERY copy must
+    # decode to the same list as copy 1, shifted by seg_n * 5 ticks (the last copy loses the frames in its final 326 samples).
+    parity, oracle_check = "n/a", "n/a"
+    if nc // seg_n >= 4 and seg_n % 131072 == 0 and not args.dcfilter:  # (the DC filter's state keeps settling: its copies are not identical)
+        from oracle.oracle import Oracle, REC_DTYPE, first_mismatch
+
         period = seg_n * 5
+        all_msgs, msgs = msgs, msgs[:chan_msgs[1]]  # channel 0 (the whole list with one channel)
+        reps = nc // seg_n
         k = msgs["ts"] // period
-        a, b = msgs[k == 1], msgs[k == reps - 2]  # the last copy loses the frames in its final 326 samples
-        same = a.size == b.size and a.size > 0 and np.array_equal(a["ts"] - period, b["ts"] - period * (reps - 2)) \
-            and np.array_equal(a["msg"], b["msg"]) and np.array_equal(a["score"], b["score"]) \
-            and np.array_equal(a["correctedbits"], b["correctedbits"])
-        parity = "periodic-ok" if same else "PERIODICITY-MISMATCH"
+        want, _ = Oracle(fmt=args.format, nfix=args.fix_bits, modeac=args.modeac).run_stream(np.concatenate([seg, seg[:131072]]))
+        bad = first_mismatch(want[want["ts"] < period], msgs[k == 0].view(REC_DTYPE))
+        oracle_check = "copy0-equals-oracle" if bad is None else f"ORACLE-MISMATCH {bad}"
+        a = msgs[k == 1]
+        fields = ("msg", "msgbits", "score", "correctedbits", "crc", "addr", "signal")
+        same = a.size > 0
+        for j in range(2, reps - 1):
+            b = msgs[k == j]
+            same = same and a.size == b.size and np.array_equal(a["ts"] - period, b["ts"] - period * j) \
+                and all(np.array_equal(a[f], b[f]) for f in fields)
+        parity = f"copies-1..{reps - 2}-identical" if same else "PERIODICITY-MISMATCH"
+        msgs = all_msgs
+    checks_ok = sum(rd.gather_counts(int(not ("MISMATCH" in parity or "MISMATCH" in oracle_check)), dev))
 
     if rank == 0:
         if args.format == "UC8" and args.fix_bits == 1 and not (args.modeac or args.dcfilter or args.dense):
@@ -279,7 +322,8 @@ def main() -> int:
         if os.path.exists(tfile):
             with open(tfile) as f:
                 t = json.load(f)
-            if t.get("samples") == n and args.format == "UC8" and not args.dcfilter:
+            # ... of this very build: the file names the kernel source it was measured on
+            if t.get("samples") == n and args.format == "UC8" and not args.dcfilter and t.get("kernel_src_sha256") == kernel_src_sha():
                 traffic = t.get("bytes_per_launch")
         scan_s = float(np.mean(scan_ms)) / 1e3
         scan_bps = 2 if args.dcfilter else bps  # --dcfilter: the scan kernel reads the converter's 16-bit magnitudes
@@ -302,12 +346,12 @@ def main() -> int:
                        "samples_per_gpu": n, "segment_samples": seg_n, "format": args.format, "fix_bits": args.fix_bits,
                        "mode_ac": bool(args.modeac), "dc_filter": bool(args.dcfilter),
                        "batches_per_step": len(cuts) - 1, "batches_in_flight": 2 if len(cuts) > 2 else 1,
-                       "channels": world, "messages_per_step": nmsgs, "survivors_per_step": st["survivors"],
-                       "full_size_check": parity, "output": args.output,
+                       "channels": world * C, "channels_per_gpu": C, "messages_per_step": nmsgs, "survivors_per_step": st["survivors"],
+                       "full_size_check": parity, "oracle_check": oracle_check, "ranks_with_checks_ok": checks_ok, "output": args.output,
                        **({"wire_bytes_per_step": int(wire_bytes.size), "wire_check": wire_check} if wire_check else {})},
             "roofline": {"bound": "hbm", "kernel": f"k_scan<{'Mag16' if args.dcfilter else args.format}>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": scan_bps * n // (len(cuts) - 1), "avg_launch_ms": scan_s * 1e3 / (len(cuts) - 1),
+                         "algorithmic_bytes_per_launch": scan_bps * n // (C * (len(cuts) - 1)), "avg_launch_ms": scan_s * 1e3 / (C * (len(cuts) - 1)),
                          "note": "per k_scan launch (one batch); the launches of a step together read the whole recording once"},
             "stage_ms": {"scan": float(np.mean(tm["scan_ms"])), "prune": float(np.mean(tm["prune_ms"])), "modeac": float(np.mean(tm["modeac_ms"])),
                          "sort": float(np.mean(tm["sort_ms"])),
