@@ -268,6 +268,22 @@ const char *rsb_version(void);
 int rsb_convert_device(rsb_ctx *ctx, const void *iq_dev, void *mag_dev, uint64_t nsamples, void *stream,
                        double *mean_level, double *mean_power);
 
+/* rsb_convert_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same kernels and same results as rsb_convert_device on a
+ * context of that format / dc_filter, but the work memory (UC8 table, integer sums, the --dcfilter scan's tile arrays and block
+ * means) is one fixed array in the library's code object, about 0.66 MB on every GPU the library runs on, held until the
+ * process ends; the call allocates nothing, frees nothing and does not wait for the device: everything is enqueued on `stream`.
+ *   nsamples      at most RSB_NOALLOC_MAX_SAMPLES per call (RSB_EINVAL and a message on stderr beyond that)
+ *   dc_state_dev  filter_dc only: two doubles in DEVICE memory, the converter_state (z1_I, z1_Q) before the call's first sample
+ *                 on entry and after its last on exit (zero them for a new stream, convert.c:476-478)
+ *   means_dev     NULL, or two doubles in DEVICE memory that receive mean_level, mean_power (valid once the stream has run)
+ * Runs on the CURRENT device.  Set-up (address look-up of the array and the UC8 table upload, a blocking copy) happens in
+ * rsb_create for its device, otherwise in the first call on a device: make that call outside stream capture.  All calls on
+ * one GPU share the array: calls that overlap in time on one GPU (other streams, other threads) race. */
+#define RSB_NOALLOC_MAX_SAMPLES (1ull << 26)
+int rsb_convert_noalloc(int input_format, int filter_dc, const void *iq_dev, uint16_t *mag_dev, uint64_t nsamples, void *stream,
+                        double *dc_state_dev, double *means_dev);
+
 /* crc.h:40-44 on the host tables the context was built with. */
 uint32_t rsb_checksum(const uint8_t *msg, int bits);
 /* modesChecksumDiagnose: returns number of bit errors (0..2) and their positions, or -1 if the

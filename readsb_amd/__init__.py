@@ -79,6 +79,7 @@ SYMBOLS = {
     "rsb_last_error": (C.c_char_p, [_VP]),
     "rsb_version": (C.c_char_p, []),
     "rsb_convert_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64, _VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rsb_convert_noalloc": (C.c_int, [C.c_int, C.c_int, _VP, _VP, C.c_uint64, _VP, _VP, _VP]),
     "rsb_checksum": (C.c_uint32, [_VP, C.c_int]),
     "rsb_diagnose": (C.c_int, [_VP, C.c_uint32, C.c_int, C.POINTER(C.c_int * 2)]),
     "rsb_crc_table_size": (C.c_int, [C.c_int, C.c_int]),

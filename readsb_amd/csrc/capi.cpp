@@ -53,6 +53,10 @@ int setup_device(rsb_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->cfg.device));
 
     int rc;
+    if ((rc = rsb_internal_noalloc_setup(c->cfg.device)) != RSB_OK) {
+        c->err = "set-up of rsb_convert_noalloc's work memory failed (see stderr)";
+        return rc;
+    }
     if ((rc = upload(c, &c->d_lut, uc8_magnitude_lut(), 65536)) != RSB_OK) return rc;
     if ((rc = upload(c, &c->d_crc_bytes, CrcTables::byte_table(), 256)) != RSB_OK) return rc;
     if ((rc = upload(c, &c->d_sbs, CrcTables::single_bit_syndromes(), 112)) != RSB_OK) return rc;

@@ -175,6 +175,8 @@ struct rsb_ctx {
     }
 };
 
+// noalloc.hip: per-device set-up of rsb_convert_noalloc's fixed work memory (the device must be current)
+int rsb_internal_noalloc_setup(int device);
 // internal entry points behind include/readsb_dropin.h (dropin.cpp)
 int rsb_internal_create_block_ctx(int fix_bits, int device, unsigned max_length, rsb_ctx **out);
 // one struct mag_buf: mag_dev = 326 overlap samples + length samples, already on the device
