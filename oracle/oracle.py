@@ -189,6 +189,9 @@ def forward_order(recs: np.ndarray) -> np.ndarray:
     return idx[:n].copy()
 
 
+REF_GPU_BIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "ref_harness_gpu")
+
+
 class RefHarness:
     """The unmodified reference, run as a child process on a temp file."""
 
@@ -197,17 +200,23 @@ class RefHarness:
         return os.access(REF_BIN, os.X_OK)
 
     @staticmethod
-    def demod(iq: np.ndarray, fmt="UC8", nfix=1, modeac=False, dc_filter=False):
+    def demod(iq: np.ndarray, fmt="UC8", nfix=1, modeac=False, dc_filter=False, verbatim=False, binary=None):
+        """verbatim=True: also (msg, verbatim) of every message, with Modes.net_verbatim set (mode_s.c:427-430).
+        binary: REF_GPU_BIN = the same harness linked against integration/gpu_path.c + libreadsb_amd.so instead of demod_2400.o / convert.o"""
         with tempfile.TemporaryDirectory() as d:
             fin, fout = os.path.join(d, "in.iq"), os.path.join(d, "out.bin")
             iq_bytes(iq).tofile(fin)
-            subprocess.run([REF_BIN, "demod", fmt, str(int(nfix)), str(int(modeac)), str(int(dc_filter)), fin, fout],
-                           check=True, stderr=subprocess.DEVNULL)
+            subprocess.run([binary or REF_BIN, "demodv" if verbatim else "demod", fmt, str(int(nfix)), str(int(modeac)), str(int(dc_filter)), fin, fout],
+                           check=True, stderr=None if binary else subprocess.DEVNULL)
             raw = np.fromfile(fout, dtype=np.uint8)
         hdr = raw[:64].view("<u8")
-        recs = raw[64:].view(REC_DTYPE)
-        assert recs.size == int(hdr[0])
-        return recs.copy(), dict(zip(STAT_NAMES, (int(x) for x in hdr[1:8])))
+        n = int(hdr[0])
+        recs = raw[64:64 + 56 * n].view(REC_DTYPE)
+        st = dict(zip(STAT_NAMES, (int(x) for x in hdr[1:8])))
+        if verbatim:
+            return recs.copy(), st, raw[64 + 56 * n:].reshape(n, 2, 14).copy()
+        assert raw.size == 64 + 56 * n
+        return recs.copy(), st
 
     @staticmethod
     def stats(iq: np.ndarray, fmt="UC8", nfix=1, modeac=False, dc_filter=False) -> dict:

@@ -14,6 +14,11 @@
  *
  * Sub-commands:
  *   demod   <fmt> <nfix> <modeac> <dcfilter> <in.iq> <out.bin>   message list + stats
+ *   demodv  (same arguments)                                       the same with Modes.net_verbatim set; behind the records: msg[14] as
+ *                                                                 delivered and verbatim[14] (mode_s.c:427-430) of every message
+ *
+ * Built a second time as oracle/_ref/ref_harness_gpu (-DGPU_PATH): the SAME harness and reference objects, but with
+ * demod_2400.o and convert.o replaced by integration/gpu_path.c + libreadsb_amd.so -- the link-level drop-in test.
  *   convert <fmt> <dcfilter> <chunk> <in.iq> <out.bin>           magnitudes + per-call means
  *   crctab  <nfix> <out.bin>                                     syndrome -> errorinfo, all 2^24 syndromes folded to a digest + table dump
  *   time    <fmt> <nfix> <modeac> <dcfilter> <in.iq> <reps>      prints seconds of convert+demod (CPU baseline, kind="reference")
@@ -50,6 +55,8 @@ struct rec {
 static struct rec *recs;
 static size_t nrecs, caprecs;
 static int capture = 1;
+static uint8_t (*verb)[2][14]; /* demodv: msg, verbatim of every captured message */
+static int capture_verbatim;
 
 /* wire capture: both writers point at a service with one pretend connection and no clients; the
  * harness drains their shared buffers after every message, so flushWrites never runs */
@@ -83,6 +90,15 @@ void __wrap_useModesMessage(struct modesMessage *mm) {
     if (nrecs == caprecs) {
         caprecs = caprecs ? caprecs * 2 : 4096;
         recs = realloc(recs, caprecs * sizeof (*recs));
+        if (capture_verbatim) verb = realloc(verb, caprecs * sizeof (*verb));
+    }
+    if (capture_verbatim) {
+        memcpy(verb[nrecs][0], mm->msg, 14);
+        memcpy(verb[nrecs][1], mm->verbatim, 14);
+        if (mm->msgbits < 112) { /* bytes past a short frame are stale stack contents in the reference */
+            memset(verb[nrecs][0] + mm->msgbits / 8, 0, 14 - mm->msgbits / 8);
+            memset(verb[nrecs][1] + mm->msgbits / 8, 0, 14 - mm->msgbits / 8);
+        }
     }
     struct rec *r = &recs[nrecs++];
     memset(r, 0, sizeof (*r));
@@ -175,7 +191,11 @@ static void run_stream(input_format_t fmt, const uint8_t *iq, size_t nbytes, int
     free(readbuf);
     free(bufs[0].data);
     free(bufs[1].data);
+#ifdef GPU_PATH
+    cleanup_converter(st);
+#else
     free(st); /* not cleanup_converter: it frees the global LUT without clearing it (convert.c:493-499) */
+#endif
 }
 
 static int cmd_demod(int argc, char **argv) {
@@ -185,6 +205,7 @@ static int cmd_demod(int argc, char **argv) {
     size_t nbytes;
     uint8_t *iq = slurp(argv[6], &nbytes);
     init_modes(nfix, modeac, dc);
+    capture_verbatim = Modes.net_verbatim = !strcmp(argv[1], "demodv");
     run_stream(fmt, iq, nbytes, modeac);
     FILE *f = fopen(argv[7], "wb");
     if (!f) { perror(argv[7]); return 2; }
@@ -198,6 +219,7 @@ static int cmd_demod(int argc, char **argv) {
         Modes.stats_current.demod_modeac};
     fwrite(hdr, sizeof (hdr), 1, f);
     fwrite(recs, sizeof (*recs), nrecs, f);
+    if (capture_verbatim) fwrite(verb, sizeof (*verb), nrecs, f);
     fclose(f);
     return 0;
 }
@@ -338,7 +360,7 @@ static int cmd_crctab(int argc, char **argv) {
 int main(int argc, char **argv) {
     int rc = 2;
     if (argc >= 2) {
-        if (!strcmp(argv[1], "demod")) rc = cmd_demod(argc, argv);
+        if (!strcmp(argv[1], "demod") || !strcmp(argv[1], "demodv")) rc = cmd_demod(argc, argv);
         else if (!strcmp(argv[1], "time")) rc = cmd_time(argc, argv);
         else if (!strcmp(argv[1], "stats")) rc = cmd_stats(argc, argv);
         else if (!strcmp(argv[1], "convert")) rc = cmd_convert(argc, argv);

@@ -17,6 +17,19 @@
 
 using namespace rsb;
 
+// Layouts of the reference's x86-64 build: struct mag_buf 48 bytes {sampleTimestamp 0, mean_level 8, mean_power 16,
+// dropped 24, length 28, sysTimestamp 32, data 40}, struct errorinfo 12 bytes.  integration/gpu_path.c asserts the same against the
+// reference's own headers where those are present.
+#include <cstddef>
+static_assert(sizeof(rsbd_mag_buf) == 48 && offsetof(rsbd_mag_buf, sampleTimestamp) == 0 && offsetof(rsbd_mag_buf, mean_level) == 8 &&
+                  offsetof(rsbd_mag_buf, mean_power) == 16 && offsetof(rsbd_mag_buf, dropped) == 24 && offsetof(rsbd_mag_buf, length) == 28 &&
+                  offsetof(rsbd_mag_buf, sysTimestamp) == 32 && offsetof(rsbd_mag_buf, data) == 40,
+              "struct mag_buf (readsb.h:298-311)");
+static_assert(sizeof(rsbd_errorinfo) == 12 && offsetof(rsbd_errorinfo, errors) == 4 && offsetof(rsbd_errorinfo, bit) == 8, "struct errorinfo (crc.h:32-38)");
+static_assert(sizeof(rsb_message) == 56 && offsetof(rsb_message, msg) == 8 && offsetof(rsb_message, msgbits) == 22 && offsetof(rsb_message, crc) == 24 &&
+                  offsetof(rsb_message, score) == 36 && offsetof(rsb_message, signal_level) == 48,
+              "rsb_message: packed, 14 dwords (k_replay_emit writes it as such)");
+
 // ================================================================================== convert.h
 
 struct rsbd_converter_state {
