@@ -147,6 +147,8 @@ int rsb_reset(rsb_ctx *ctx);
 
 /* icaoFilterAdd (icao_filter.c:71-95): what --show-only does at start-up (readsb.c:249-250). */
 int rsb_filter_add(rsb_ctx *ctx, uint32_t addr);
+/* The same for n addresses in one go, in the order given (what a shard does with the filter contents handed over by the shard before it). */
+int rsb_filter_add_many(rsb_ctx *ctx, const uint32_t *addrs, size_t n);
 /* One icaoFilterExpire flip (icao_filter.c:147-161) as an explicit event between submits; the
  * reference drives it from wall-clock time, which a reproducible batch run cannot. */
 int rsb_filter_expire(rsb_ctx *ctx);
@@ -177,8 +179,9 @@ int rsb_filter_export(rsb_ctx *ctx, uint32_t *out, size_t cap, size_t *n_out);
  * at `iq_dev` (2 bytes/sample for UC8, 4 for SC16/SC16Q11, interleaved I,Q as convert.c reads
  * them), on HIP stream `stream` (a hipStream_t passed as void*, NULL = default stream).
  * Asynchronous.  The stream position must be a multiple of RSB_BLOCK_SAMPLES at entry (every
- * batch but the last of a recording is a whole number of blocks).  The buffer must stay valid
- * until rsb_collect returns. */
+ * batch but the last of a recording is a whole number of blocks).  A batch that is short OR EMPTY ends
+ * the recording: nothing may be submitted after it before rsb_seek / rsb_reset.  The buffer must stay
+ * valid until rsb_collect returns. */
 int rsb_submit(rsb_ctx *ctx, const void *iq_dev, uint64_t nsamples, void *stream);
 
 /* Wait for the submitted batch, run the surviving candidates through the reference's sequential
@@ -254,6 +257,11 @@ typedef struct rsb_forwarder rsb_forwarder;
 rsb_forwarder *rsb_forwarder_create(void);
 void rsb_forwarder_destroy(rsb_forwarder *f);
 int rsb_forwarder_push(rsb_forwarder *f, const rsb_message *in, size_t n, rsb_message *out, size_t cap, size_t *n_out);
+
+/* Host merge of several channels' (or shards') message lists into ONE list in timestamp order (BASELINE north star: "results are
+ * merged on the host in timestamp order").  The reference has one channel and no such step; the order defined here: ascending
+ * timestampMsg, ties in list order and, within a list, in emission order (stable).  *n_out = total; RSB_EOVERFLOW if > cap. */
+int rsb_merge_by_timestamp(const rsb_message *const *lists, const size_t *counts, size_t nlists, rsb_message *out, size_t cap, size_t *n_out);
 
 int rsb_get_stats(const rsb_ctx *ctx, rsb_stats *st);
 int rsb_get_timing(const rsb_ctx *ctx, rsb_timing *t);

@@ -52,7 +52,8 @@ typedef void (*rsbd_iq_convert_fn)(void *iq_data, uint16_t *mag_data, unsigned n
 
 /* filter_dc != 0 selects the DC-block converters (convert.c:113-162, :164-213, :374-423) as a chunked
  * linear-recurrence scan: magnitudes within +-1 LSB of the sequential float32 IIR, state carried across
- * calls (DESIGN.md "DC filter").  The function returned takes
+ * calls (DESIGN.md "DC filter"); its coefficients are those of sample_rate = 2400000 (convert.c:480-488), any other rate
+ * with filter_dc is refused like an unknown format.  The function returned takes
  * HOST buffers, as the reference's do (it stages through device memory owned by the state).
  * out_mean_level / out_mean_power are the reference's bit for bit, also for the SC16 formats, whose
  * float32 running sums (convert.c:226-262) are taken in sample order on the device. */

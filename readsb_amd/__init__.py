@@ -64,6 +64,7 @@ SYMBOLS = {
     "rsb_destroy": (None, [_VP]),
     "rsb_reset": (C.c_int, [_VP]),
     "rsb_filter_add": (C.c_int, [_VP, C.c_uint32]),
+    "rsb_filter_add_many": (C.c_int, [_VP, _VP, _SZ]),
     "rsb_filter_expire": (C.c_int, [_VP]),
     "rsb_submit": (C.c_int, [_VP, _VP, C.c_uint64, _VP]),
     "rsb_seek": (C.c_int, [_VP, C.c_uint64, _VP, C.c_int]),
@@ -94,6 +95,7 @@ SYMBOLS = {
     "rsb_stream_push": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint64]),
     "rsb_stream_flush": (C.c_int, [_VP]),
     "rsb_stream_close": (C.c_int, [_VP]),
+    "rsb_merge_by_timestamp": (C.c_int, [_VP, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_host_replay": (C.c_int, [C.c_int, C.c_uint64, _VP, _SZ, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
 }
 
@@ -187,6 +189,10 @@ class Channel:
 
     def filter_add(self, addr):
         self._check(self.l.rsb_filter_add(self.h, addr), "rsb_filter_add")
+
+    def filter_add_many(self, addrs):
+        addrs = np.ascontiguousarray(addrs, dtype=np.uint32)
+        self._check(self.l.rsb_filter_add_many(self.h, addrs.ctypes.data if addrs.size else None, addrs.size), "rsb_filter_add_many")
 
     def filter_expire(self):
         self._check(self.l.rsb_filter_expire(self.h), "rsb_filter_expire")
@@ -301,6 +307,21 @@ def wire_encode(msgs: np.ndarray, wire: str = "beast", mlat: bool = True) -> np.
     if rc != 0:
         raise RsbError(f"rsb_wire_encode rc={rc}")
     return out[:nb.value].copy()
+
+
+def merge_by_timestamp(lists) -> np.ndarray:
+    """rsb_merge_by_timestamp: several channels' / shards' message lists -> one list in timestamp order (stable)"""
+    lists = [np.ascontiguousarray(m, dtype=MSG_DTYPE) for m in lists]
+    n = len(lists)
+    ptrs = (_VP * max(1, n))(*[m.ctypes.data for m in lists])
+    counts = (_SZ * max(1, n))(*[m.size for m in lists])
+    total = sum(m.size for m in lists)
+    out = np.zeros(max(1, total), dtype=MSG_DTYPE)
+    got = _SZ()
+    rc = lib().rsb_merge_by_timestamp(ptrs, counts, n, out.ctypes.data, out.size, C.byref(got))
+    if rc != 0:
+        raise RsbError(f"rsb_merge_by_timestamp rc={rc}")
+    return out[:got.value]
 
 
 class Forwarder:

@@ -264,7 +264,10 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
         c->tables_valid = false;  // entries folded to 0 that the host does not know of
         return 0;
     }
-    if (direct) *direct = parts_out ? 1 : 0;
+    // with to_host the emit kernel has written the first min(accepted, host_cap) records into the caller's buffer: they are delivered
+    // (rsb_collect's contract for a short buffer: the first cap records and RSB_EOVERFLOW); nothing of this batch is in r.out then
+    (void)parts_out;
+    if (direct) *direct = to_host ? 1 : 0;
     if (nnew) {
         c->h_new_adders.resize(nnew);
         HIP_TRY(c, hipMemcpy(c->h_new_adders.data(), c->d_new_adders, nnew * sizeof(uint2), hipMemcpyDeviceToHost));
@@ -350,15 +353,34 @@ int rsb_reset(rsb_ctx *c) {
     return reset_device(c);
 }
 
-int rsb_filter_add(rsb_ctx *c, uint32_t addr) {
-    if (!c) return RSB_EINVAL;
-    addr &= 0xffffffu;
-    c->replay.filter().add(addr);
+int rsb_filter_add(rsb_ctx *c, uint32_t addr) { return rsb_filter_add_many(c, &addr, 1); }
+
+int rsb_filter_add_many(rsb_ctx *c, const uint32_t *addrs, size_t n) {
+    if (!c || (!addrs && n)) return RSB_EINVAL;
+    if (n == 0) return RSB_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    uint32_t word = 0;
-    HIP_TRY(c, hipMemcpy(&word, c->d_bitmap + (addr >> 5), 4, hipMemcpyDeviceToHost));
-    word |= 1u << (addr & 31);
-    HIP_TRY(c, hipMemcpy(c->d_bitmap + (addr >> 5), &word, 4, hipMemcpyHostToDevice));
+    // the scans of pending batches set bits of the superset with atomics: wait for them before the host touches its words
+    for (rsb_slot &b : c->slots)
+        if (b.pending) HIP_TRY(c, hipEventSynchronize(b.ev[3]));
+    if (n <= 8) {
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t addr = addrs[i] & 0xffffffu;
+            c->replay.filter().add(addr);
+            uint32_t word = 0;
+            HIP_TRY(c, hipMemcpy(&word, c->d_bitmap + (addr >> 5), 4, hipMemcpyDeviceToHost));
+            word |= 1u << (addr & 31);
+            HIP_TRY(c, hipMemcpy(c->d_bitmap + (addr >> 5), &word, 4, hipMemcpyHostToDevice));
+        }
+    } else {  // one round trip of the whole 2 MiB set instead of two blocking copies per address
+        std::vector<uint32_t> words((1u << 24) / 32);
+        HIP_TRY(c, hipMemcpy(words.data(), c->d_bitmap, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t addr = addrs[i] & 0xffffffu;
+            c->replay.filter().add(addr);
+            words[addr >> 5] |= 1u << (addr & 31);
+        }
+        HIP_TRY(c, hipMemcpy(c->d_bitmap, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     c->filter_dirty = true;
     return RSB_OK;
 }
@@ -488,7 +510,9 @@ static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t n
     ++c->submitted;
     if (!c->block_mode) {
         c->submit_pos += nsamples;
-        if (nsamples % kBlock != 0) c->submit_finished = true;
+        // a short batch ends the recording, and so does an empty one (the reference publishes a zero-length block only at EOF,
+        // sdr_ifile.c:213-225): nothing may follow it without rsb_seek / rsb_reset, so no carry is needed behind it
+        if (nsamples == 0 || nsamples % kBlock != 0) c->submit_finished = true;
     }
     return RSB_OK;
 }
@@ -799,7 +823,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
 
     if (!c->block_mode) {
         c->stream_pos += b.pending_n;
-        if (b.pending_n % kBlock != 0) c->finished = true;
+        if (b.pending_n == 0 || b.pending_n % kBlock != 0) c->finished = true;
     }
 
     if (n_out) *n_out = n;

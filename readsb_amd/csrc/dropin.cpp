@@ -79,9 +79,14 @@ void convert_entry(void *iq_data, uint16_t *mag_data, unsigned nsamples, rsbd_co
 
 }  // namespace
 
-extern "C" rsbd_iq_convert_fn rsbd_init_converter(int format, double /*sample_rate: only the DC filter uses it (convert.c:480-488)*/, int filter_dc,
-                                                  rsbd_converter_state **out_state) {
+extern "C" rsbd_iq_convert_fn rsbd_init_converter(int format, double sample_rate, int filter_dc, rsbd_converter_state **out_state) {
     if (out_state) *out_state = nullptr;
+    if (filter_dc && sample_rate != 2400000.0) {
+        // convert.c:480-488 derives dc_a / dc_b from the sample rate; the device converters carry the 2.4 MS/s constants
+        // (the only rate readsb runs this path at, readsb.c:193)
+        std::fprintf(stderr, "no suitable converter for format=%d dc=%d at sample rate %.0f (the DC filter is built for 2400000)\n", format, filter_dc, sample_rate);
+        return nullptr;
+    }
     if (format < RSB_UC8 || format > RSB_SC16Q11 || !out_state) {
         std::fprintf(stderr, "no suitable converter for format=%d dc=%d\n", format, filter_dc);  // convert.c:460-464
         return nullptr;

@@ -51,6 +51,11 @@ int collect_one(rsb_stream *st) {
 int submit_staged(rsb_stream *st) {
     if (!st->filled) return RSB_OK;
     const int k = st->cur;
+    // a --dcfilter context holds one batch at a time (one magnitude buffer): finish the batch in flight first
+    if (st->in_flight >= (unsigned)st->c->nslots) {
+        const int rc = collect_one(st);
+        if (rc != RSB_OK) return rc;
+    }
     ST_TRY(st, hipMemcpyAsync(st->d_stage[k], st->h_stage[k], (size_t)st->filled * st->bps, hipMemcpyHostToDevice, st->copy_stream));
     const int rc = rsb_submit(st->c, st->d_stage[k], st->filled, st->copy_stream);
     if (rc != RSB_OK) return rc;
@@ -141,6 +146,10 @@ int rsb_stream_push(rsb_stream *st, const void *iq_host, uint32_t nsamples, uint
         if (rc != RSB_OK) return rc;
     }
     if (!nsamples) return RSB_OK;
+    if (st->filled + nsamples > (uint64_t)st->blocks * kBlock) {  // an earlier submit failed and left the buffer full
+        c->err = "rsb_stream_push: the staging buffer is full (an earlier push failed)";
+        return RSB_ESTATE;
+    }
     std::memcpy(st->h_stage[st->cur] + (size_t)st->filled * st->bps, iq_host, (size_t)nsamples * st->bps);
     st->filled += nsamples;
     if (nsamples < kBlock) {

@@ -2,6 +2,9 @@
 // two-message forwarding rule of useModesMessage (mode_s.c:2163-2175).  No device code here.
 #include "wire.hpp"
 
+#include <algorithm>
+#include <vector>
+
 #include <new>
 #include <unordered_map>
 #include <vector>
@@ -65,6 +68,41 @@ int rsb_forwarder_push(rsb_forwarder *f, const rsb_message *in, size_t n, rsb_me
     }
     *n_out = k;
     return k > cap ? RSB_EOVERFLOW : RSB_OK;
+}
+
+int rsb_merge_by_timestamp(const rsb_message *const *lists, const size_t *counts, size_t nlists, rsb_message *out, size_t cap, size_t *n_out) {
+    if ((!lists || !counts) && nlists) return RSB_EINVAL;
+    if ((!out && cap) || !n_out) return RSB_EINVAL;
+    size_t total = 0;
+    for (size_t l = 0; l < nlists; ++l) {
+        if (!lists[l] && counts[l]) return RSB_EINVAL;
+        total += counts[l];
+    }
+    *n_out = total;
+    if (total > cap) return RSB_EOVERFLOW;
+    // A channel's list is in the reference's emission order: per 131072-sample block its Mode S messages, then its Mode A/C
+    // messages (readsb.c:883-886), i.e. sorted runs but not one sorted list.  Stable sort of (timestamp, list, position): messages
+    // with equal timestamps keep channel order, and within a channel the order they were emitted in.
+    struct Ref {
+        uint64_t ts;
+        uint32_t list;
+        uint32_t pos_hi;
+        uint64_t pos;
+    };
+    std::vector<Ref> refs;
+    refs.reserve(total);
+    bool sorted = true;
+    uint64_t last = 0;
+    for (size_t l = 0; l < nlists; ++l)
+        for (size_t i = 0; i < counts[l]; ++i) {
+            const uint64_t ts = lists[l][i].timestamp;
+            sorted = sorted && ts >= last;
+            last = ts;
+            refs.push_back(Ref{ts, (uint32_t)l, 0, i});
+        }
+    if (!sorted) std::stable_sort(refs.begin(), refs.end(), [](const Ref &a, const Ref &b) { return a.ts < b.ts; });
+    for (size_t k = 0; k < total; ++k) out[k] = lists[refs[k].list][refs[k].pos];
+    return RSB_OK;
 }
 
 }  // extern "C"

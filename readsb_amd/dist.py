@@ -68,6 +68,14 @@ def gather_messages(msgs: np.ndarray, device: torch.device) -> list[np.ndarray]:
     return [o.cpu().numpy()[:c * MSG_DTYPE.itemsize].view(MSG_DTYPE).copy() for o, c in zip(out, counts)]
 
 
+def merge_channels(msgs: np.ndarray, device: torch.device) -> np.ndarray:
+    """Every rank's message list gathered and merged on the host in timestamp order (BASELINE north star; the merge itself is the
+    library's rsb_merge_by_timestamp: stable, ties in rank order).  The same merged list on every rank."""
+    from . import merge_by_timestamp
+
+    return merge_by_timestamp(gather_messages(msgs, device))
+
+
 # ---- one recording decoded in shards (include/readsb_amd.h, "one recording in shards"; SURVEY.md section 8e) ----------------
 #
 # Segment k = samples [k * seg, (k + 1) * seg) of the recording, seg a multiple of 131072.  In round j rank r scans segment
@@ -87,8 +95,7 @@ def shard_finish(ch, all_adders: np.ndarray, filter_in: np.ndarray | None, cap: 
     """steps 2 and 3 on one rank: widen the superset, take over the filter, collect -> (messages, filter to pass on)"""
     ch.superset_add(all_adders)
     if filter_in is not None:
-        for a in np.unique(filter_in):
-            ch.filter_add(int(a))
+        ch.filter_add_many(np.unique(filter_in))  # one call: the scan of this shard is pending, every add would wait and copy
     msgs = ch.collect(cap).copy()
     return msgs, ch.filter_export()
 

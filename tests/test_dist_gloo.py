@@ -39,7 +39,8 @@ def _rank_main(rank, world, port, outdir):
     slowest = rd.max_over_ranks(1.0 + rank, dev)
     everyone = rd.gather_messages(msgs, dev)
     empty = rd.gather_messages(msgs[:0] if rank == 0 else msgs[:3], dev)  # a rank with nothing to report
-    np.savez(os.path.join(outdir, f"rank{rank}.npz"), counts=np.array(counts), slowest=slowest, mine=msgs.view(np.uint8),
+    merged = rd.merge_channels(msgs, dev)  # the host merge by timestamp (rsb_merge_by_timestamp)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), counts=np.array(counts), slowest=slowest, mine=msgs.view(np.uint8), merged=merged.view(np.uint8),
              **{f"ch{i}": m.view(np.uint8) for i, m in enumerate(everyone)}, empty_sizes=np.array([m.size for m in empty]))
     rd.barrier(dev)
     dist.destroy_process_group()
@@ -58,6 +59,15 @@ def test_two_ranks_two_channels(tmp_path, built):
             assert np.array_equal(z[r][f"ch{ch}"], z[ch]["mine"])
         assert list(z[r]["empty_sizes"]) == [0, 3]
     assert not np.array_equal(z[0]["mine"][:56], z[1]["mine"][:56])  # channels are different recordings
+    # the merged list: every channel's messages, ascending timestamps, ties in channel order -- the same on both ranks
+    import readsb_amd
+
+    both = np.concatenate([z[ch]["mine"].view(readsb_amd.MSG_DTYPE) for ch in range(world)])
+    want = both[np.argsort(both["ts"], kind="stable")]
+    for r in range(world):
+        got = z[r]["merged"].view(readsb_amd.MSG_DTYPE)
+        assert got.size == sum(sizes) and np.all(np.diff(got["ts"].astype(np.int64)) >= 0)
+        assert got.tobytes() == want.tobytes()
 
 
 class _FakeChannel:
@@ -84,6 +94,10 @@ class _FakeChannel:
 
     def filter_add(self, a):
         self.filter.add(int(a))
+
+    def filter_add_many(self, addrs):
+        for a in addrs:
+            self.filter.add(int(a))
 
     def collect(self, cap):
         import readsb_amd

@@ -414,3 +414,49 @@ def test_long_recording_dense_aggressive_modeac(built):
     assert first_mismatch(want, got.view(REC_DTYPE)) is None
     assert ch.stats()["demod_modeac"] == wst["modeac"]
     ch.close()
+
+
+def test_pinned_output_smaller_than_the_batch(built):
+    """rsb_collect's contract for a short buffer -- the first cap records are stored, *n_out is the batch's count, RSB_EOVERFLOW
+    is returned -- also when `out` is pinned host memory that the emit kernel writes itself."""
+    import ctypes as C
+
+    import torch
+
+    name = "mixed_fix1"
+    sc, kw = SCENARIOS[name]
+    iq = generate(sc)
+    gold, _, _ = load_demod(name)
+    dev_iq = torch.from_numpy(iq).cuda()
+    cap = 100
+    pinned = torch.full(((cap + 8) * 56,), 0xEE, dtype=torch.uint8).pin_memory().numpy()
+    for first in (True, False):  # twice: the second call finds the previous batch's records in the device list
+        ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], max_batch_samples=sc.n_samples)
+        if not first:
+            ch.submit(dev_iq.data_ptr(), sc.n_samples)
+            assert ch.collect(cap=gold.size + 10).size == gold.size
+            ch.reset()
+        ch.submit(dev_iq.data_ptr(), sc.n_samples)
+        n = C.c_size_t()
+        rc = ch.l.rsb_collect(ch.h, pinned.ctypes.data, cap, C.byref(n))
+        assert rc == -4 and n.value == gold.size
+        assert first_mismatch(gold[:cap], pinned[:cap * 56].view(REC_DTYPE)) is None
+        assert bool((pinned[cap * 56:] == 0xEE).all())  # nothing behind the caller's cap
+        ch.close()
+
+
+def test_empty_batch_ends_the_recording(built):
+    """An empty rsb_submit is the reference's zero-length last block (sdr_ifile.c:213-225): it ends the recording, so no later batch
+    can pick up a stale overlap; rsb_seek / rsb_reset start the next one."""
+    sc, kw = SCENARIOS["exact_2_blocks"]
+    iq = generate(sc)
+    want, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=131072)
+    parts = [ch.process_host(iq[:131072]), ch.process_host(iq[:0])]
+    assert parts[1].size == 0
+    with pytest.raises(readsb_amd.RsbError):
+        ch.process_host(iq[131072:])
+    ch.seek(131072, iq[131072 - 326:131072])
+    parts.append(ch.process_host(iq[131072:]))
+    assert first_mismatch(want, np.concatenate(parts).view(REC_DTYPE)) is None
+    ch.close()

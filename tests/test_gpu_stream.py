@@ -80,3 +80,24 @@ def test_call_sequence_errors(built):
     want, _ = Oracle(fmt="UC8", nfix=1, modeac=False).run_stream(iq)
     assert first_mismatch(want, st.messages().view(REC_DTYPE)) is None
     ch.close()
+
+
+@pytest.mark.parametrize("fmt", ["UC8", "SC16"])
+def test_dcfilter_stream_equals_batched_host_calls(fmt, built):
+    """A --dcfilter context holds ONE batch at a time (one magnitude buffer): the stream has to collect the batch in flight
+    before it submits the next.  Five batches + a ragged tail; the same blocks through rsb_process_host on a second context
+    of the same kind give the same messages, record for record (same kernels, same DC state carried from batch to batch)."""
+    sc = Scenario(9 * BLOCK + 4321, seed=41, fmt=fmt, frames_per_sec=3000, dc_offset=0.02)
+    iq = generate(sc)
+    ch = readsb_amd.Channel(fmt=fmt, fix_bits=1, dc_filter=True, max_batch_samples=2 * BLOCK)
+    st = readsb_amd.Stream(ch, 2)
+    push_blocks(st, iq)
+    st.close()
+    got = st.messages()
+    assert len(st.parts) >= 5 and ch.stats()["samples_processed"] == sc.n_samples
+    ch.close()
+    ref = readsb_amd.Channel(fmt=fmt, fix_bits=1, dc_filter=True, max_batch_samples=2 * BLOCK)
+    want = ref.process_stream_host(iq, 2)
+    ref.close()
+    assert want.size > 100
+    assert first_mismatch(want.view(REC_DTYPE), got.view(REC_DTYPE)) is None

@@ -132,3 +132,28 @@ def test_stream_entry_points_reject_bad_arguments_without_a_device():
     assert l.rsb_stream_push(None, None, 0, 0) == -1
     assert l.rsb_stream_flush(None) == -1
     assert l.rsb_stream_close(None) == -1
+
+
+def test_merge_by_timestamp_is_a_stable_merge():
+    """rsb_merge_by_timestamp: lists that are sorted runs (Mode A/C messages behind each block's Mode S messages), equal timestamps
+    across lists, an empty list; too small an output is refused."""
+    import ctypes as C
+
+    rng = np.random.Generator(np.random.PCG64(5))
+    lists = []
+    for k, n in enumerate((700, 0, 1300, 5)):
+        m = np.zeros(n, dtype=readsb_amd.MSG_DTYPE)
+        m["ts"] = np.sort(rng.integers(0, 4000, size=n))  # many ties
+        if n > 100:
+            m["ts"][50:80] = m["ts"][50:80][::-1]          # a run out of order, as a block's Mode A/C tail is
+        m["addr"] = k
+        m["crc"] = np.arange(n)
+        lists.append(m)
+    got = readsb_amd.merge_by_timestamp(lists)
+    both = np.concatenate(lists)
+    assert got.tobytes() == both[np.argsort(both["ts"], kind="stable")].tobytes()
+    assert readsb_amd.merge_by_timestamp([]).size == 0
+    out = np.zeros(3, dtype=readsb_amd.MSG_DTYPE)
+    n = C.c_size_t()
+    ptrs, counts = (C.c_void_p * 1)(lists[0].ctypes.data), (C.c_size_t * 1)(lists[0].size)
+    assert readsb_amd.lib().rsb_merge_by_timestamp(ptrs, counts, 1, out.ctypes.data, 3, C.byref(n)) == -4 and n.value == 700
