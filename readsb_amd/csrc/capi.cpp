@@ -86,6 +86,7 @@ int setup_device(rsb_ctx *c) {
     c->scan_grid = scan_grid_size(c->cfg.device);
     if (const char *e = std::getenv("RSB_STAGE_LIMIT")) c->stage_limit = std::atoi(e);  // ablation timing only
     if (const char *e = std::getenv("RSB_ABL")) c->debug_flags = std::atoi(e);
+    if (const char *e = std::getenv("RSB_FORCE_SORT")) c->force_sort = std::atoi(e) != 0;  // A/B and tests: the atomic prune + radix sort
     if (const char *e = std::getenv("RSB_SCAN_GRID")) c->scan_grid = std::atoi(e);
     if (c->cfg.scan_workgroups && (int)c->cfg.scan_workgroups < c->scan_grid) c->scan_grid = (int)c->cfg.scan_workgroups;
     if (c->scan_grid < 1) c->scan_grid = 1;
@@ -95,6 +96,8 @@ int setup_device(rsb_ctx *c) {
         rsb_slot &b = c->slots[k];
         HIP_TRY(c, hipMalloc((void **)&b.d_items, (size_t)c->item_cap * sizeof(ItemRec)));
         HIP_TRY(c, hipMalloc((void **)&b.d_region_counts, (size_t)c->scan_grid * kScanWavesPerGroup * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&b.d_region_kept, (size_t)c->scan_grid * kScanWavesPerGroup * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&b.d_region_masks, ((size_t)c->item_cap / 64 + (size_t)c->scan_grid * kScanWavesPerGroup) * sizeof(uint64_t)));
         for (int w = 0; w < 2; ++w) {
             HIP_TRY(c, hipMalloc((void **)&b.d_skeys[w], (size_t)c->surv_item_cap * sizeof(uint64_t)));
             HIP_TRY(c, hipMalloc((void **)&b.d_sinfo[w], (size_t)c->surv_item_cap * sizeof(uint32_t)));
@@ -320,7 +323,7 @@ void rsb_destroy(rsb_ctx *c) {
                     c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_blk_start, c->d_new_adders, c->d_addr_upload, c->d_means,
                     c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge};
     for (rsb_slot &b : c->slots) {
-        void *sp[] = {b.d_items, b.d_region_counts, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
+        void *sp[] = {b.d_items, b.d_region_counts, b.d_region_kept, b.d_region_masks, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
         for (void *p : sp)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : b.ev)
@@ -468,13 +471,30 @@ int rsb_filter_export(rsb_ctx *c, uint32_t *out, size_t cap, size_t *n_out) {
     return RSB_OK;
 }
 
+// The filter-superset prune of a scanned batch.  Normally the ordered compaction (the scan's item regions are sorted runs in
+// stream order: no sort needed afterwards); the atomic prune + radix sort remain for batches with marker items (exact
+// statistics) and are fallen back to at collect time when a scan wavefront overflowed one of its LDS queues (then some items
+// sit in the shared region, out of order).
+static int enqueue_prune(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, hipStream_t s) {
+    b.pruned_in_order = !a.emit_dead && !c->force_sort;
+    if (b.pruned_in_order)
+        HIP_TRY(c, launch_prune_ordered(a, s));
+    else
+        HIP_TRY(c, launch_prune(a, s));
+    return RSB_OK;
+}
+
 static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
     HIP_TRY(c, hipMemsetAsync(b.d_counters, 0, kCntAlloc * sizeof(uint32_t), s));
     HIP_TRY(c, hipMemsetAsync(b.d_region_counts, 0, (size_t)a.n_regions * sizeof(uint32_t), s));
     HIP_TRY(c, hipEventRecord(b.ev[0], s));
     if (c->run_modes) HIP_TRY(c, launch_scan(a, c->scan_grid, s));
     HIP_TRY(c, hipEventRecord(b.ev[1], s));
-    if (c->run_modes && !c->defer_prune) HIP_TRY(c, launch_prune(a, s));
+    b.pruned_in_order = false;
+    if (c->run_modes && !c->defer_prune) {
+        const int rc = enqueue_prune(c, b, a, s);
+        if (rc != RSB_OK) return rc;
+    }
     HIP_TRY(c, hipEventRecord(b.ev[2], s));
     b.means_on_device = nullptr;
     if ((c->run_ac || c->exact_stats) && nsamples) {
@@ -653,7 +673,10 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     // everything from here on runs on the context's own stream, behind this batch's scan and beside the next batch's
     hipStream_t s = c->replay_stream;
     HIP_TRY(c, hipStreamWaitEvent(s, b.ev[3], 0));
-    if (c->defer_prune && c->run_modes) HIP_TRY(c, launch_prune(b.pending_args, s));  // against the superset as the caller has widened it
+    if (c->defer_prune && c->run_modes) {  // against the superset as the caller has widened it
+        const int rc = enqueue_prune(c, b, b.pending_args, s);
+        if (rc != RSB_OK) return rc;
+    }
     uint32_t cnt[kCntCount];
     HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -679,10 +702,29 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         c->finished = true;
         return RSB_EOVERFLOW;
     }
-    const uint32_t n_items = cnt[kCntSurvItems];
     const BatchArgs &a = b.pending_args;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    HIP_TRY(c, launch_sort(a, n_items, c->d_sort_temp, c->sort_temp_bytes, &c->sorted_buf, s));
+    if (b.pruned_in_order && cnt[kCntItems] != 0 && c->run_modes) {
+        // a scan wavefront overflowed an LDS queue: its per-thread path put items into the shared region, out of order.  Prune once
+        // more, this time with the sort behind it.
+        HIP_TRY(c, hipMemsetAsync(b.d_counters + kCntSurvItems, 0, 2 * sizeof(uint32_t), s));
+        HIP_TRY(c, launch_prune(a, s));
+        HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        b.pruned_in_order = false;
+        ++c->sort_fallbacks;
+        if (std::getenv("RSB_VERBOSE")) std::fprintf(stderr, "readsb_amd: batch pruned again with the sort (%u items took a per-thread path)\n", cnt[kCntItems]);
+        if (cnt[kCntOverflow] || cnt[kCntSurvItems] > c->surv_item_cap) {
+            c->err = "device queue overflow: kept items (lower rsb_config.queue_div)";
+            c->finished = true;
+            return RSB_EOVERFLOW;
+        }
+    }
+    const uint32_t n_items = cnt[kCntSurvItems];
+    if (b.pruned_in_order)
+        c->sorted_buf = 0;  // packed in stream order by the prune itself
+    else
+        HIP_TRY(c, launch_sort(a, n_items, c->d_sort_temp, c->sort_temp_bytes, &c->sorted_buf, s));
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
 
     // the sequential half: on the device, unless asked otherwise or the device path declines the batch

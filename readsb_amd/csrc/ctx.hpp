@@ -15,6 +15,9 @@
 struct rsb_slot {
     rsb::ItemRec *d_items = nullptr;
     uint32_t *d_region_counts = nullptr;
+    uint32_t *d_region_kept = nullptr;
+    uint64_t *d_region_masks = nullptr;
+    bool pruned_in_order = false;     // the pending batch went through launch_prune_ordered: its kept items need no sort
     uint64_t *d_skeys[2] = {nullptr, nullptr};
     uint32_t *d_sinfo[2] = {nullptr, nullptr};
     rsb::AcCand *d_ac = nullptr;
@@ -55,6 +58,8 @@ struct rsb_ctx {
     uint32_t item_cap = 0, surv_item_cap = 0, surv_cap = 0, ac_cap = 0;
     int scan_grid = 512;
     int sorted_buf = 0;
+    bool force_sort = false;          // RSB_FORCE_SORT: always the atomic prune + radix sort (A/B runs)
+    unsigned sort_fallbacks = 0;      // batches that had to be pruned again with the sort (a scan wavefront overflowed an LDS queue)
     int stage_limit = 99;
     int debug_flags = 0;
     uint32_t *d_bitmap = nullptr;
@@ -149,10 +154,14 @@ struct rsb_ctx {
             const uint64_t nstrips = (n + 2 + rsb::kScanStrip - 1) / rsb::kScanStrip, need = (nstrips + rsb::kScanWavesPerGroup - 1) / rsb::kScanWavesPerGroup;
             const uint32_t grid = (uint32_t)(need < (uint64_t)scan_grid ? (need ? need : 1) : (uint64_t)scan_grid);
             a.n_regions = grid * (uint32_t)rsb::kScanWavesPerGroup;
+            a.strips_per_wave = (uint32_t)((nstrips + a.n_regions - 1) / a.n_regions);
         }
         a.shared_cap = item_cap / 16;
         a.item_region = (item_cap - a.shared_cap) / a.n_regions;
         a.region_counts = b.d_region_counts;
+        a.region_kept = b.d_region_kept;
+        a.region_masks = b.d_region_masks;
+        a.mask_stride = (a.item_region + 63) / 64;
         a.surv_item_cap = surv_item_cap;
         for (int w = 0; w < 2; ++w) {
             a.skeys[w] = b.d_skeys[w];

@@ -71,6 +71,10 @@ struct BatchArgs {
     uint32_t n_regions;
     uint32_t shared_cap;
     uint32_t *region_counts; // items written per wave region
+    uint32_t *region_kept;   // ordered prune: kept items per region, then their exclusive sum
+    uint64_t *region_masks;  // ... and one keep mask per 64 items, mask_stride masks per region
+    uint32_t mask_stride;
+    uint32_t strips_per_wave;// every scan wavefront takes this many consecutive strips
     uint32_t surv_item_cap;
     uint64_t *skeys[2];    // kept items: sort key g << 3 | phase (ping-pong buffers for the radix sort)
     uint32_t *sinfo[2];    // ... and their info words
@@ -117,6 +121,7 @@ constexpr uint32_t kNever = 0xffffffffu;
 int scan_grid_size(int device);
 hipError_t launch_scan(const BatchArgs &a, int grid, hipStream_t s);
 hipError_t launch_prune(const BatchArgs &a, hipStream_t s);
+hipError_t launch_prune_ordered(const BatchArgs &a, hipStream_t s);
 // sorts the n_items kept items by (g, phase), derives the ascending list of distinct offsets
 // (count -> counters[kCntSurvivors]) and re-slices each of them into a Survivor record
 size_t sort_temp_bytes(uint32_t max_items);
