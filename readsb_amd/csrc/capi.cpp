@@ -128,6 +128,8 @@ int setup_device(rsb_ctx *c) {
         for (int w = 0; w < 2; ++w) HIP_TRY(c, hipMalloc((void **)&c->d_first_add[w], sizeof(uint32_t) << 24));
         HIP_TRY(c, hipMalloc((void **)&c->d_blk_counts, c->nblocks_cap * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void **)&c->d_blk_start, (c->nblocks_cap + 1) * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_blk_base, (c->nblocks_cap + 1) * sizeof(uint32_t)));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_pin, (1 + kCntCount + c->nblocks_cap + 2 * rsb_ctx::kPinAdders) * sizeof(uint32_t), hipHostMallocDefault));
         HIP_TRY(c, hipMalloc((void **)&c->d_new_adders, rsb_ctx::kNewAddersCap * sizeof(uint2)));
         HIP_TRY(c, hipMalloc((void **)&c->d_addr_upload, 8 * IcaoFilter::kSlots * sizeof(uint32_t)));  // 2 x kSlots members, up to 6 x kSlots stale entries
         // the message records of the device replay reuse the candidate records' memory (one path runs per batch)
@@ -170,11 +172,18 @@ int mirror_filter(rsb_ctx *c, hipStream_t s) {
 
 constexpr int kMaxReplayIterations = 16;
 
+bool emit_direct_enabled() {
+    static const bool on = std::getenv("RSB_EMIT_DIRECT") && std::atoi(std::getenv("RSB_EMIT_DIRECT")) != 0;
+    return on;
+}
+
 // Returns 1 when the batch was replayed on the device (messages in c->d_surv as rsb_message records,
 // counters in cnt), 0 when the host path has to take it, < 0 on error.
 // direct_out (optional): the caller's record buffer.  If the device can address it (pinned host memory), the emit kernel
 // writes the records there itself (*direct = 1) and no device -> host copy follows.
-int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint32_t cnt[kCntCount], rsb_message *direct_out = nullptr,
+// n_items: the number of kept items, or -- count_on_device -- the host's bound on it (the kernels then read the count the prune left in
+// the batch's counters; cnt[] is filled from the device together with the first round's results, and the caller checks it afterwards).
+int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_device, hipStream_t s, uint32_t cnt[kCntCount], rsb_message *direct_out = nullptr,
                   size_t direct_cap = 0, int *direct = nullptr) {
     const BatchArgs &a = b.pending_args;
     int rc;
@@ -184,9 +193,13 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
     r.keys = a.skeys[c->sorted_buf];
     r.info = a.sinfo[c->sorted_buf];
     r.n_items = n_items;
+    r.n_dev = count_on_device ? b.d_counters + kCntSurvItems : nullptr;
+    r.n_cap = c->surv_item_cap;
+    r.counters = b.d_counters;
     r.acc = a.sinfo[c->sorted_buf ^ 1];
-    r.acc_idx = (uint32_t *)a.skeys[c->sorted_buf ^ 1];
-    r.cand = r.acc_idx + r.n_items;  // the spare key buffer holds 2 x 32 bits per item: acc_idx (written after the iterations) and cand
+    r.acc_rank = (uint32_t *)a.skeys[c->sorted_buf ^ 1];  // the spare key buffer holds 2 x 32 bits per item: the accepted items' ranks and cand
+    r.cand = r.acc_rank + c->surv_item_cap;
+    r.blk_base = c->d_blk_base;
     r.blk_counts = c->d_blk_counts;
     r.blk_start = c->d_blk_start;
     r.nblocks = (uint32_t)((b.pending_n + kBlock - 1) / kBlock);
@@ -205,7 +218,9 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
     // hipHostRegister, e.g. torch's pin_memory): the emit kernel's stores then are the device -> host transfer.
     bool to_host = false;
     r.host_out = nullptr;
-    if (direct_out && direct && direct_cap) {
+    // (measured on MI355X: a DMA copy of the finished list moves 41 MB at 56 GB/s beside a running scan kernel without slowing it,
+    // the kernel's own stores over PCIe reach 50 GB/s and hold CUs meanwhile -- so the direct path is opt-in: RSB_EMIT_DIRECT=1)
+    if (emit_direct_enabled() && direct_out && direct && direct_cap) {
         const uint32_t hcap = (uint32_t)(direct_cap < 0xffffffffull ? direct_cap : 0xffffffffull);
         hipPointerAttribute_t lo_attr, hi_attr;
         const bool lo_ok = hipPointerGetAttributes(&lo_attr, direct_out) == hipSuccess && lo_attr.type == hipMemoryTypeHost && lo_attr.devicePointer;
@@ -226,15 +241,33 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
         r.t_cur = c->d_first_add[c->first_cur];
         r.t_next = c->d_first_add[c->first_cur ^ 1];
         HIP_TRY(c, launch_replay_iteration(a, r, s));
-        uint32_t changed = 0;
-        HIP_TRY(c, hipMemcpyAsync(&changed, b.d_counters + kCntChanged, sizeof(changed), hipMemcpyDeviceToHost, s));
+        // what the host reads back lands in pinned memory (one wait, no staging copies): [changed | counters | block counts | new adders]
+        uint32_t *pin = c->h_pin;
+        uint32_t &changed = pin[0];
+        changed = 0;
+        HIP_TRY(c, hipMemcpyAsync(&pin[0], b.d_counters + kCntChanged, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         if (it == 0) {
             HIP_TRY(c, launch_replay_select(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
             HIP_TRY(c, launch_replay_emit(a, r, s));
-            HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipMemcpyAsync(c->h_blk_counts.data(), c->d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(pin + 1, b.d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(pin + 1 + kCntCount, c->d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(pin + 1 + kCntCount + c->nblocks_cap, c->d_new_adders, rsb_ctx::kPinAdders * sizeof(uint2), hipMemcpyDeviceToHost, s));
         }
         HIP_TRY(c, hipStreamSynchronize(s));
+        if (it == 0) {
+            std::memcpy(cnt, pin + 1, kCntCount * sizeof(uint32_t));
+            std::memcpy(c->h_blk_counts.data(), pin + 1 + kCntCount, r.nblocks * sizeof(uint32_t));
+            if (count_on_device) {
+                // now the host sees what the prune left: anything the kernels' clamps papered over ends the batch here
+                if (cnt[kCntOverflow] || cnt[kCntSurvItems] > c->surv_item_cap || cnt[kCntItems] != 0) {
+                    c->filter_dirty = true;
+                    c->tables_valid = false;  // the rounds above ran on a list that does not count
+                    return -1000;             // the caller looks at cnt[]
+                }
+                r.n_items = cnt[kCntSurvItems];  // exact from here on
+                r.n_dev = nullptr;
+            }
+        }
         ++c->timing.replay_iterations;
         if (!changed) {
             converged = true;
@@ -251,11 +284,15 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
         return 0;
     }
     if (!emitted) {
+        uint32_t *pin = c->h_pin;
         HIP_TRY(c, launch_replay_select(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
         HIP_TRY(c, launch_replay_emit(a, r, s));
-        HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(c->h_blk_counts.data(), c->d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(pin + 1, b.d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(pin + 1 + kCntCount, c->d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(pin + 1 + kCntCount + c->nblocks_cap, c->d_new_adders, rsb_ctx::kPinAdders * sizeof(uint2), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
+        std::memcpy(cnt, pin + 1, kCntCount * sizeof(uint32_t));
+        std::memcpy(c->h_blk_counts.data(), pin + 1 + kCntCount, r.nblocks * sizeof(uint32_t));
     }
     HIP_TRY(c, launch_replay_fold(r, s));  // the batch's new members become "in the filter before the next batch" (asynchronous)
     const bool parts_out = to_host && cnt[kCntAccepted] <= r.host_cap && cnt[kCntAccepted] <= r.out_cap;
@@ -273,7 +310,10 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, hipStream_t s, uint
     if (direct) *direct = to_host ? 1 : 0;
     if (nnew) {
         c->h_new_adders.resize(nnew);
-        HIP_TRY(c, hipMemcpy(c->h_new_adders.data(), c->d_new_adders, nnew * sizeof(uint2), hipMemcpyDeviceToHost));
+        if (nnew <= rsb_ctx::kPinAdders)  // came along with the counters
+            std::memcpy(c->h_new_adders.data(), c->h_pin + 1 + kCntCount + c->nblocks_cap, nnew * sizeof(uint2));
+        else
+            HIP_TRY(c, hipMemcpy(c->h_new_adders.data(), c->d_new_adders, nnew * sizeof(uint2), hipMemcpyDeviceToHost));
         std::sort(c->h_new_adders.begin(), c->h_new_adders.end(), [](const uint2 &x, const uint2 &y) { return x.x < y.x; });
         for (const uint2 &e : c->h_new_adders) {
             c->replay.filter().add(e.y);  // in the order the reference learns them
@@ -320,7 +360,7 @@ void rsb_destroy(rsb_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
-                    c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_blk_start, c->d_new_adders, c->d_addr_upload, c->d_means,
+                    c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_blk_start, c->d_blk_base, c->d_new_adders, c->d_addr_upload, c->d_means,
                     c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge};
     for (rsb_slot &b : c->slots) {
         void *sp[] = {b.d_items, b.d_region_counts, b.d_region_kept, b.d_region_masks, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
@@ -330,6 +370,7 @@ void rsb_destroy(rsb_ctx *c) {
             if (ev) (void)hipEventDestroy(ev);
     }
     if (c->replay_stream) (void)hipStreamDestroy(c->replay_stream);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (void *p : c->d_carry)
         if (p) (void)hipFree(p);
     for (void *p : ptrs)
@@ -677,9 +718,39 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         const int rc = enqueue_prune(c, b, b.pending_args, s);
         if (rc != RSB_OK) return rc;
     }
+    const BatchArgs &a = b.pending_args;
+    const size_t nblocks = (size_t)((b.pending_n + kBlock - 1) / kBlock);
+    c->h_blk_counts.resize(nblocks + 1);
+    int on_device = 0, direct_parts = 0;
+    c->timing.replay_iterations = 0;
     uint32_t cnt[kCntCount];
-    HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    std::memset(cnt, 0, sizeof(cnt));
+    // The usual batch needs no word from the device before its replay is enqueued: the prune leaves the kept items packed in
+    // order and their number in the counters, the replay kernels read it there, and the host waits ONCE, for the first
+    // round's results and the counters together.  Anything unusual (a scan wavefront overflowed an LDS queue, a device queue
+    // is full, marker items, host replay, records written straight to the caller's buffer) takes the step-by-step path below.
+    bool replayed = false;
+#ifndef RSB_STAGE_CLOCKS
+    if (c->run_modes && b.pruned_in_order && !c->host_replay_only && !a.emit_dead && !a.keep_all && !emit_direct_enabled() && !(c->debug_flags & 256)) {
+        HIP_TRY(c, hipEventRecord(c->ev[0], s));
+        HIP_TRY(c, hipEventRecord(c->ev[1], s));
+        c->sorted_buf = 0;
+        uint64_t bound = b.pending_n / 128;
+        if (bound < 4096) bound = 4096;
+        if (bound > c->surv_item_cap) bound = c->surv_item_cap;
+        on_device = device_replay(c, b, (uint32_t)bound, true, s, cnt);
+        if (on_device == -1000)
+            on_device = 0;  // cnt[] says why: looked at below
+        else if (on_device < 0)
+            return on_device;
+        else
+            replayed = true;
+    }
+#endif
+    if (!replayed && !(cnt[kCntOverflow] | cnt[kCntItems] | cnt[kCntSurvItems])) {
+        HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
     if (c->debug_flags & 256) {  // ablation runs only (RSB_ABL): survivors of the Mode A/C kernel's first two stages
         uint32_t dbg[kCntAlloc];
         HIP_TRY(c, hipMemcpy(dbg, b.d_counters, sizeof(dbg), hipMemcpyDeviceToHost));
@@ -702,46 +773,44 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         c->finished = true;
         return RSB_EOVERFLOW;
     }
-    const BatchArgs &a = b.pending_args;
-    HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    if (b.pruned_in_order && cnt[kCntItems] != 0 && c->run_modes) {
-        // a scan wavefront overflowed an LDS queue: its per-thread path put items into the shared region, out of order.  Prune once
-        // more, this time with the sort behind it.
-        HIP_TRY(c, hipMemsetAsync(b.d_counters + kCntSurvItems, 0, 2 * sizeof(uint32_t), s));
-        HIP_TRY(c, launch_prune(a, s));
-        HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        b.pruned_in_order = false;
-        ++c->sort_fallbacks;
-        if (std::getenv("RSB_VERBOSE")) std::fprintf(stderr, "readsb_amd: batch pruned again with the sort (%u items took a per-thread path)\n", cnt[kCntItems]);
-        if (cnt[kCntOverflow] || cnt[kCntSurvItems] > c->surv_item_cap) {
-            c->err = "device queue overflow: kept items (lower rsb_config.queue_div)";
-            c->finished = true;
-            return RSB_EOVERFLOW;
+    uint32_t n_items = cnt[kCntSurvItems];
+    if (!replayed) {
+        HIP_TRY(c, hipEventRecord(c->ev[0], s));
+        if (b.pruned_in_order && cnt[kCntItems] != 0 && c->run_modes) {
+            // a scan wavefront overflowed an LDS queue: its per-thread path put items into the shared region, out of order.  Prune once
+            // more, this time with the sort behind it.
+            HIP_TRY(c, hipMemsetAsync(b.d_counters + kCntSurvItems, 0, 2 * sizeof(uint32_t), s));
+            HIP_TRY(c, launch_prune(a, s));
+            HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            b.pruned_in_order = false;
+            ++c->sort_fallbacks;
+            if (std::getenv("RSB_VERBOSE")) std::fprintf(stderr, "readsb_amd: batch pruned again with the sort (%u items took a per-thread path)\n", cnt[kCntItems]);
+            if (cnt[kCntOverflow] || cnt[kCntSurvItems] > c->surv_item_cap) {
+                c->err = "device queue overflow: kept items (lower rsb_config.queue_div)";
+                c->finished = true;
+                return RSB_EOVERFLOW;
+            }
         }
-    }
-    const uint32_t n_items = cnt[kCntSurvItems];
-    if (b.pruned_in_order)
-        c->sorted_buf = 0;  // packed in stream order by the prune itself
-    else
-        HIP_TRY(c, launch_sort(a, n_items, c->d_sort_temp, c->sort_temp_bytes, &c->sorted_buf, s));
-    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+        n_items = cnt[kCntSurvItems];
+        if (b.pruned_in_order)
+            c->sorted_buf = 0;  // packed in stream order by the prune itself
+        else
+            HIP_TRY(c, launch_sort(a, n_items, c->d_sort_temp, c->sort_temp_bytes, &c->sorted_buf, s));
+        HIP_TRY(c, hipEventRecord(c->ev[1], s));
 
-    // the sequential half: on the device, unless asked otherwise or the device path declines the batch
-    const size_t nblocks = (size_t)((b.pending_n + kBlock - 1) / kBlock);
-    c->h_blk_counts.resize(nblocks + 1);
-    int on_device = 0, direct_parts = 0;
-    c->timing.replay_iterations = 0;
-    if (!c->run_modes) {
-        on_device = 1;  // nothing to replay: a Mode A/C only pass of the drop-in
-        std::memset(cnt + kCntChanged, 0, (kCntCount - kCntChanged) * sizeof(uint32_t));
-        c->h_blk_counts.assign(nblocks + 1, 0);
-    } else if (!c->host_replay_only && !a.emit_dead && !a.keep_all) {
-        // records wanted and nothing to interleave: the list can leave in parts while it is still being written
-        const bool parts_ok = !wire && out && cnt[kCntAc] == 0;
-        on_device = device_replay(c, b, n_items, s, cnt, parts_ok ? out : nullptr, cap, &direct_parts);
-        if (on_device < 0) return on_device;
-        if (!on_device) direct_parts = 0;  // (whatever the kernel wrote to the buffer, the host path rewrites it)
+        // the sequential half: on the device, unless asked otherwise or the device path declines the batch
+        if (!c->run_modes) {
+            on_device = 1;  // nothing to replay: a Mode A/C only pass of the drop-in
+            std::memset(cnt + kCntChanged, 0, (kCntCount - kCntChanged) * sizeof(uint32_t));
+            c->h_blk_counts.assign(nblocks + 1, 0);
+        } else if (!c->host_replay_only && !a.emit_dead && !a.keep_all) {
+            // records wanted and nothing to interleave: the list can leave in parts while it is still being written
+            const bool parts_ok = !wire && out && cnt[kCntAc] == 0;
+            on_device = device_replay(c, b, n_items, false, s, cnt, parts_ok ? out : nullptr, cap, &direct_parts);
+            if (on_device < 0) return on_device;
+            if (!on_device) direct_parts = 0;  // (whatever the kernel wrote to the buffer, the host path rewrites it)
+        }
     }
     uint32_t nsurv = 0;
     if (!on_device) {

@@ -81,7 +81,9 @@ struct rsb_ctx {
     bool exact_stats = false;       // RSB_FLAG_EXACT_STATS: every gated offset goes to the host replay, block means are kept
     std::vector<double> h_blk_mean_power;
     std::vector<uint64_t> h_blk_sums;
-    uint32_t *d_blk_counts = nullptr, *d_blk_start = nullptr;
+    uint32_t *d_blk_counts = nullptr, *d_blk_start = nullptr, *d_blk_base = nullptr;
+    uint32_t *h_pin = nullptr;        // pinned: what the host reads back per batch (changed flag, counters, block counts, first new adders)
+    static constexpr uint32_t kPinAdders = 1024;
     uint2 *d_new_adders = nullptr;
     uint32_t *d_addr_upload = nullptr;
     uint32_t out_cap = 0;

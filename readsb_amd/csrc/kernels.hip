@@ -1231,11 +1231,22 @@ __device__ __forceinline__ bool combo_decodes(uint32_t combo, bool member) {
 __device__ __forceinline__ bool combo_is_short(uint32_t combo) { return combo == kComboApShort || (combo >= kComboDf11Iid0 && combo <= kComboDf11IidX + 1); }
 __device__ __forceinline__ bool combo_adds(uint32_t combo) { return combo == kComboDf11Iid0 || combo == kComboDf17; }  // mode_s.c:717-726
 
-// first item of every 131072-sample block in the sorted item list (blk_start[nblocks] = n_items)
+// The number of kept items is the prune's result and stays on the device (counters[kCntSurvItems]): the replay kernels are
+// enqueued behind the prune without the host learning it first, with grids sized from the host's bound r.n_items.
+__device__ __forceinline__ uint32_t items_of(const ReplayArgs &r) { return r.n_dev ? min(*r.n_dev, r.n_cap) : r.n_items; }
+
+// first item of every 131072-sample block in the sorted item list (blk_start[nblocks] = n_items); also clears the counters the
+// replay's later kernels add to
 __global__ __launch_bounds__(kThreads) void k_replay_bounds(const ReplayArgs r) {
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i <= r.n_items; i += gridDim.x * kThreads) {
+    const uint32_t n_items = items_of(r);
+    if (blockIdx.x == 0 && threadIdx.x < 6 && r.counters) {
+        static_assert(kCntNewAdders == kCntAccepted + 1 && kCntAccE0 == kCntAccepted + 2 && kCntAccE2 == kCntAccepted + 4, "one run of counters");
+        if (threadIdx.x < 5) r.counters[kCntAccepted + threadIdx.x] = 0;
+        else r.counters[kCntChanged] = 0;
+    }
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i <= n_items; i += gridDim.x * kThreads) {
         const int64_t prev = i == 0 ? -1 : (int64_t)min((uint64_t)r.nblocks, (r.keys[i - 1] >> 3) / kBlock);
-        const int64_t cur = i == r.n_items ? (int64_t)r.nblocks : (int64_t)min((uint64_t)r.nblocks, (r.keys[i] >> 3) / kBlock);
+        const int64_t cur = i == n_items ? (int64_t)r.nblocks : (int64_t)min((uint64_t)r.nblocks, (r.keys[i] >> 3) / kBlock);
         for (int64_t b = prev + 1; b <= cur; ++b) r.blk_start[b] = i;
     }
 }
@@ -1245,7 +1256,9 @@ __global__ __launch_bounds__(kThreads) void k_replay_bounds(const ReplayArgs r) 
 // decodeModesMessage would take it.  cand[i] = 0, or for such an offset: (best score + 1) | best item's distance << 16 |
 // (112-bit frame) << 20.  Fully parallel: the sequential part is left to k_replay_walk.
 __global__ __launch_bounds__(kThreads) void k_replay_score(const ReplayArgs r) {
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads) {
+    const uint32_t n_items = items_of(r);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && r.counters) r.counters[kCntChanged] = 0;  // (k_replay_compare of this round raises it)
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_items; i += gridDim.x * kThreads) {
         r.acc[i] = 0;
         const uint32_t g = (uint32_t)(r.keys[i] >> 3);
         uint32_t out = 0;
@@ -1256,7 +1269,7 @@ __global__ __launch_bounds__(kThreads) void k_replay_score(const ReplayArgs r) {
 #pragma unroll
             for (uint32_t d = 0; d < 5; ++d) {
                 const uint32_t e = i + d;
-                if (e >= r.n_items || (d && (uint32_t)(r.keys[e] >> 3) != g)) break;
+                if (e >= n_items || (d && (uint32_t)(r.keys[e] >> 3) != g)) break;
                 const uint32_t info = r.info[e], combo = item_combo(info);
                 if (combo == kComboMarker) continue;
                 const bool member = r.t_cur[item_value(info)] <= g;  // added by a message at an earlier offset
@@ -1280,7 +1293,7 @@ __global__ __launch_bounds__(kThreads) void k_replay_score(const ReplayArgs r) {
 __global__ __launch_bounds__(kThreads) void k_replay_walk(const ReplayArgs r) {
     __shared__ uint32_t cand_g[kThreads / 64][64];
     __shared__ uint32_t cand_len[kThreads / 64][64];
-    __shared__ uint32_t cand_ok[kThreads / 64][64];
+    __shared__ uint32_t cand_ok[kThreads / 64][64];   // 0, or 1 + the message's rank among the block's accepted messages
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * (kThreads / 64) + wave;
     if (b >= r.nblocks) return;  // whole wavefronts leave; no workgroup barrier below
@@ -1312,13 +1325,41 @@ __global__ __launch_bounds__(kThreads) void k_replay_walk(const ReplayArgs r) {
             const uint32_t cg = cand_g[wave][k];
             const bool take = cg >= next_j;
             if (take) next_j = cg + cand_len[wave][k] + 1;
-            if (lane == 0) cand_ok[wave][k] = take;
+            if (lane == 0) cand_ok[wave][k] = take ? accepted + 1 : 0u;
             accepted += take;
         }
         wave_sync();
-        if (cand && cand_ok[wave][pos]) r.acc[i + ((c >> 16) & 15u)] = c & 0xffffu;
+        if (cand && cand_ok[wave][pos]) {
+            r.acc[i + ((c >> 16) & 15u)] = c & 0xffffu;
+            r.acc_rank[i + ((c >> 16) & 15u)] = cand_ok[wave][pos] - 1;  // k_replay_emit: the record's place = the block's base + this
+        }
     }
     if (lane == 0) r.blk_counts[b] = accepted;
+}
+
+// accepted messages before every 131072-sample block (blk_base[nblocks] = all of the batch's, also to counters[kCntAccepted])
+__global__ __launch_bounds__(1024) void k_replay_blkbase(const ReplayArgs r) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x, per = (r.nblocks + 1023) / 1024, lo = min(r.nblocks, t * per), hi = min(r.nblocks, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; ++b) sum += r.blk_counts[b];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t add = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t b = lo; b < hi; ++b) {
+        r.blk_base[b] = run;
+        run += r.blk_counts[b];
+    }
+    if (t == 1023) {
+        r.blk_base[r.nblocks] = part[1023];
+        r.counters[kCntAccepted] = part[1023];
+    }
 }
 
 // min(offset + 1) per address over the items that add their address to the filter (mode_s.c:717-726), into a "first added at"
@@ -1340,35 +1381,42 @@ __global__ __launch_bounds__(kThreads) void k_replay_table_min(const ReplayArgs 
         val[i] = kNever;
     }
     __syncthreads();
-    const uint32_t lo = blockIdx.x * (uint32_t)kMinItemsPerGroup, hi = min(r.n_items, lo + (uint32_t)kMinItemsPerGroup);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += kThreads) {
-        if (!SEED && r.acc[i] == 0) continue;
-        const uint32_t info = r.info[i];
-        if (!combo_adds(item_combo(info))) continue;
-        const uint32_t v = item_value(info), g1 = (uint32_t)(r.keys[i] >> 3) + 1;
-        uint32_t h = (v * 0x9E3779B1u) >> 21;
-        bool placed = false;
-        for (int probe = 0; probe < 16 && !placed; ++probe) {
-            const uint32_t k = atomicCAS(&key[h], kNever, v);
-            if (k == kNever || k == v) {
-                atomicMin(&val[h], g1);
-                placed = true;
+    const uint32_t n_items = items_of(r);
+    for (uint32_t lo = blockIdx.x * (uint32_t)kMinItemsPerGroup; lo < n_items; lo += gridDim.x * (uint32_t)kMinItemsPerGroup) {  // (one run per workgroup when the host's bound holds)
+        const uint32_t hi = min(n_items, lo + (uint32_t)kMinItemsPerGroup);
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+            if (!SEED && r.acc[i] == 0) continue;
+            const uint32_t info = r.info[i];
+            if (!combo_adds(item_combo(info))) continue;
+            const uint32_t v = item_value(info), g1 = (uint32_t)(r.keys[i] >> 3) + 1;
+            uint32_t h = (v * 0x9E3779B1u) >> 21;
+            bool placed = false;
+            for (int probe = 0; probe < 16 && !placed; ++probe) {
+                const uint32_t k = atomicCAS(&key[h], kNever, v);
+                if (k == kNever || k == v) {
+                    atomicMin(&val[h], g1);
+                    placed = true;
+                }
+                h = (h + 1) & (kMinSlots - 1);
             }
-            h = (h + 1) & (kMinSlots - 1);
+            if (!placed && table[v] > g1) atomicMin(&table[v], g1);  // (a run with more distinct addresses than the table holds)
         }
-        if (!placed && table[v] > g1) atomicMin(&table[v], g1);  // (a run with more distinct addresses than the table holds)
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kMinSlots; i += kThreads) {
-        const uint32_t v = key[i];
-        if (v != kNever && table[v] > val[i]) atomicMin(&table[v], val[i]);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kMinSlots; i += kThreads) {
+            const uint32_t v = key[i];
+            if (v != kNever && table[v] > val[i]) atomicMin(&table[v], val[i]);
+            key[i] = kNever;
+            val[i] = kNever;
+        }
+        __syncthreads();
     }
 }
 
 // over the items that can add an address: did the table move / reset / list / fold
 __global__ __launch_bounds__(kThreads) void k_replay_compare(const ReplayArgs r, uint32_t *changed) {
+    const uint32_t n_items = items_of(r);
     bool any = false;
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_items; i += gridDim.x * kThreads) {
         const uint32_t info = r.info[i];
         if (!combo_adds(item_combo(info))) continue;
         const uint32_t v = item_value(info);
@@ -1377,7 +1425,8 @@ __global__ __launch_bounds__(kThreads) void k_replay_compare(const ReplayArgs r,
     if (any) *changed = 1;
 }
 __global__ __launch_bounds__(kThreads) void k_replay_reset(const ReplayArgs r, uint32_t *table) {
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads) {
+    const uint32_t n_items = items_of(r);
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_items; i += gridDim.x * kThreads) {
         const uint32_t info = r.info[i];
         if (!combo_adds(item_combo(info))) continue;
         const uint32_t v = item_value(info);
@@ -1385,7 +1434,8 @@ __global__ __launch_bounds__(kThreads) void k_replay_reset(const ReplayArgs r, u
     }
 }
 __global__ __launch_bounds__(kThreads) void k_replay_list(const ReplayArgs r, uint32_t *counters) {
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads) {
+    const uint32_t n_items = items_of(r);
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_items; i += gridDim.x * kThreads) {
         const uint32_t info = r.info[i];
         if (!combo_adds(item_combo(info)) || r.acc[i] == 0) continue;
         const uint32_t v = item_value(info), g1 = (uint32_t)(r.keys[i] >> 3) + 1;
@@ -1396,7 +1446,8 @@ __global__ __launch_bounds__(kThreads) void k_replay_list(const ReplayArgs r, ui
     }
 }
 __global__ __launch_bounds__(kThreads) void k_replay_fold(const ReplayArgs r) {
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < r.n_items; i += gridDim.x * kThreads) {
+    const uint32_t n_items = items_of(r);
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_items; i += gridDim.x * kThreads) {
         const uint32_t info = r.info[i];
         if (!combo_adds(item_combo(info))) continue;
         const uint32_t v = item_value(info);
@@ -1455,25 +1506,32 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t nacc = a.counters[kCntAccepted];
-    if (nacc > r.out_cap) nacc = r.out_cap;
-    if (r.host_out && nacc > r.host_cap) nacc = r.host_cap;
+    // The wavefront walks the sorted item list 64 items at a time; the accepted ones among them (nearly all) are consecutive
+    // messages of the output: place = accepted messages before the item's 131072-sample block + its rank within the block.
+    const uint32_t n_items = items_of(r);
+    const uint32_t out_cap = r.host_out ? min(r.out_cap, r.host_cap) : r.out_cap;
     uint32_t by_errors[3] = {0, 0, 0};  // wave-uniform
     constexpr int kRawVecs = (FMT == kFmtUC8 || FMT == kFmtMag16) ? 1 : 2;
     constexpr int kBps = 2 * kRawVecs;
     const uint32_t nthreads = gridDim.x * kT;
-    for (uint32_t base = (blockIdx.x * kT + threadIdx.x) & ~63u; base < nacc; base += nthreads) {
+    for (uint32_t base = (blockIdx.x * kT + threadIdx.x) & ~63u; base < n_items; base += nthreads) {
         const uint32_t mi = base + lane;
-        const bool valid = mi < nacc;
-        uint32_t g = 0, phase = 0, info = kComboDf17 << 27, score = 0;
-        if (valid) {
-            const uint32_t idx = r.acc_idx[mi];
-            const uint64_t key = r.keys[idx];
-            g = (uint32_t)(key >> 3);
-            phase = (uint32_t)key & 7u;
-            info = r.info[idx];
-            score = r.acc[idx] - 1;
+        uint32_t g = 0, phase = 0, info = kComboDf17 << 27, score = 0, place = 0;
+        bool valid = false;
+        if (mi < n_items) {
+            const uint32_t acc = r.acc[mi];
+            if (acc) {
+                const uint64_t key = r.keys[mi];
+                g = (uint32_t)(key >> 3);
+                phase = (uint32_t)key & 7u;
+                info = r.info[mi];
+                score = acc - 1;
+                place = r.blk_base[g / kBlock] + r.acc_rank[mi];
+                valid = place < out_cap;
+            }
         }
+        const uint64_t vm = __ballot(valid);
+        if (!vm) continue;  // wave-uniform
         const uint32_t combo = item_combo(info);
         const bool lng = !combo_is_short(combo);
         const uint32_t nbits = lng ? 112 : 56;
@@ -1598,7 +1656,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
             const bool df11 = combo >= kComboDf11Iid0 && combo <= kComboDf11IidX + 1;
             const double signal_power = (double)pw / 65535.0 / 65535.0;
             const double level = signal_power / (double)signal_len;
-            uint32_t *o = &sh.rec[threadIdx.x >> 6][lane * 14];  // rsb_message, packed: 14 dwords
+            uint32_t *o = &sh.rec[threadIdx.x >> 6][lanes_below(vm) * 14];  // rsb_message, packed: 14 dwords; the wavefront's records in output order
             o[0] = (uint32_t)ts;
             o[1] = (uint32_t)(ts >> 32);
             o[2] = __builtin_bswap32(w[0]);  // msg[0..3]
@@ -1616,12 +1674,13 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
             o[13] = (uint32_t)(lv >> 32);
         }
         {
-            // The wavefront's records [base, base + nv) are contiguous in the list: 3584 bytes as 224 x 16-byte stores, each
-            // instruction covering 1 KB without holes.  That is what makes writing straight into the caller's pinned host
-            // buffer (r.host_out: no device -> host copy afterwards) run at PCIe rate; dword stores at a 56-byte stride do not.
+            // The wavefront's nv records are consecutive in the list, from the place of its first accepted item on: contiguous
+            // 16-byte stores where the run is whole and aligned (what makes writing straight into pinned host memory run at PCIe
+            // rate), dword stores otherwise.
             wave_sync();
-            const uint32_t nv = min(64u, nacc - base);
-            rsb_message *dst = (r.host_out ? r.host_out : r.out) + base;
+            const uint32_t nv = (uint32_t)__popcll(vm);
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)place, (int)__builtin_ctzll(vm));
+            rsb_message *dst = (r.host_out ? r.host_out : r.out) + first;
             const uint32_t *src = sh.rec[threadIdx.x >> 6];
             if (nv == 64 && ((uintptr_t)dst & 15u) == 0) {
 #pragma unroll
@@ -2391,20 +2450,23 @@ inline unsigned item_grid(uint32_t n) {
 }
 }  // namespace
 
+namespace {
+inline unsigned run_grid(uint32_t n) {  // k_replay_table_min: one workgroup per run of kMinItemsPerGroup items
+    const unsigned g = (n + kMinItemsPerGroup - 1) / kMinItemsPerGroup;
+    return g < 1 ? 1 : g;
+}
+}  // namespace
+
 hipError_t launch_replay_bounds(const ReplayArgs &r, hipStream_t s) {
     hipLaunchKernelGGL(k_replay_bounds, dim3(item_grid(r.n_items + 1)), dim3(kThreads), 0, s, r);
-    // (a small grid: the items are in ascending offset order, so the threads' later rounds find their address already entered
-    // and skip the atomic -- with one thread per item, thousands of atomics queued on each aircraft's entry)
-    if (r.n_items && r.t_cur) hipLaunchKernelGGL(k_replay_table_min<true>, dim3((r.n_items + kMinItemsPerGroup - 1) / kMinItemsPerGroup), dim3(kThreads), 0, s, r);
+    if (r.n_items && r.t_cur) hipLaunchKernelGGL(k_replay_table_min<true>, dim3(run_grid(r.n_items)), dim3(kThreads), 0, s, r);
     return hipGetLastError();
 }
 
 hipError_t launch_replay_iteration(const BatchArgs &a, const ReplayArgs &r, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(&a.counters[kCntChanged], 0, sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    if (r.n_items) hipLaunchKernelGGL(k_replay_score, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);
+    if (r.n_items) hipLaunchKernelGGL(k_replay_score, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);  // (clears counters[kCntChanged])
     hipLaunchKernelGGL(k_replay_walk, dim3((r.nblocks + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, s, r);
-    if (r.n_items) hipLaunchKernelGGL(k_replay_table_min<false>, dim3((r.n_items + kMinItemsPerGroup - 1) / kMinItemsPerGroup), dim3(kThreads), 0, s, r);
+    if (r.n_items) hipLaunchKernelGGL(k_replay_table_min<false>, dim3(run_grid(r.n_items)), dim3(kThreads), 0, s, r);
     if (r.n_items) hipLaunchKernelGGL(k_replay_compare, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, &a.counters[kCntChanged]);
     return hipGetLastError();
 }
@@ -2414,14 +2476,12 @@ hipError_t launch_replay_reset(const BatchArgs &, const ReplayArgs &r, uint32_t 
     return hipGetLastError();
 }
 
-hipError_t launch_replay_select(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(&a.counters[kCntAccepted], 0, 5 * sizeof(uint32_t), s);  // accepted, new adders, by errors
-    if (e != hipSuccess || r.n_items == 0) return e;
-    hipLaunchKernelGGL(k_replay_list, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, a.counters);
-    e = hipGetLastError();
+hipError_t launch_replay_select(const BatchArgs &a, const ReplayArgs &r, void *, size_t, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(&a.counters[kCntNewAdders], 0, 4 * sizeof(uint32_t), s);  // new adders, by errors (a repeated round starts over)
     if (e != hipSuccess) return e;
-    return hipcub::DeviceSelect::Flagged(temp, temp_bytes, hipcub::CountingInputIterator<uint32_t>(0), r.acc, r.acc_idx, &a.counters[kCntAccepted],
-                                         (int)r.n_items, s);
+    hipLaunchKernelGGL(k_replay_blkbase, dim3(1), dim3(1024), 0, s, r);
+    if (r.n_items) hipLaunchKernelGGL(k_replay_list, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, a.counters);
+    return hipGetLastError();
 }
 
 hipError_t launch_replay_fold(const ReplayArgs &r, hipStream_t s) {
@@ -2435,7 +2495,8 @@ hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream
         auto kern = k_replay_emit<decltype(F)::value>;
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmitShared));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(512), dim3(64 * kEmitWaves), sizeof(EmitShared), s, a, r);
+        const unsigned g = (r.n_items + 64 * kEmitWaves - 1) / (64 * kEmitWaves);
+        hipLaunchKernelGGL(kern, dim3(g < 1 ? 1 : (g > 512 ? 512 : g)), dim3(64 * kEmitWaves), sizeof(EmitShared), s, a, r);
         return hipGetLastError();
     });
 }

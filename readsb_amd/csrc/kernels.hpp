@@ -99,10 +99,14 @@ struct BatchArgs {
 struct ReplayArgs {
     const uint64_t *keys;    // sorted: g << 3 | phase
     const uint32_t *info;    // the items' info words, same order
-    uint32_t n_items;
+    uint32_t n_items;        // the host's BOUND on the number of items (sizes the grids); the kernels take the count itself from ...
+    const uint32_t *n_dev;   // ... here (the prune's counters[kCntSurvItems]), clamped to n_cap; nullptr: n_items is exact
+    uint32_t n_cap;
+    uint32_t *counters;      // the batch's device counters (kernels.hpp enum)
     uint32_t *acc;           // per item: score + 1 if this (offset, phase) is decoded and accepted, else 0
-    uint32_t *cand;          // per item: k_replay_score's verdict for the offset that starts there (scratch: shares acc_idx's buffer)
-    uint32_t *acc_idx;       // indices of the accepted items, ascending
+    uint32_t *cand;          // per item: k_replay_score's verdict for the offset that starts there (scratch)
+    uint32_t *acc_rank;      // per accepted item: its rank among the accepted messages of its 131072-sample block (k_replay_walk)
+    uint32_t *blk_base;      // accepted messages before every block, nblocks + 1 entries (k_replay_blkbase)
     uint32_t *t_cur;         // 2^24 x u32: 0 = in the filter before this batch, g + 1 = first added by the message at
     uint32_t *t_next;        //             offset g of this batch, 0xffffffff = never
     uint32_t *blk_start;     // first item of every 131072-sample block, nblocks + 1 entries (launch_replay_bounds)
@@ -133,8 +137,8 @@ hipError_t launch_replay_bounds(const ReplayArgs &r, hipStream_t s);  // once pe
 hipError_t launch_replay_iteration(const BatchArgs &a, const ReplayArgs &r, hipStream_t s);
 hipError_t launch_replay_reset(const BatchArgs &a, const ReplayArgs &r, uint32_t *table, hipStream_t s);
 hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s);
-// the two halves of launch_replay_finish on their own: the list of accepted items (count -> counters[kCntAccepted]), and
-// their records (to r.out, or straight to r.host_out)
+// the two halves of launch_replay_finish on their own: where every accepted message goes (block bases; total ->
+// counters[kCntAccepted]; the addresses learned -> r.new_adders), and the records (to r.out, or straight to r.host_out)
 hipError_t launch_replay_select(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s);
 hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream_t s);
 // (launch_replay_select leaves the tables alone; this folds the batch's new members into them once the fixed point is certain)
