@@ -199,6 +199,7 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devic
     r.acc = a.sinfo[c->sorted_buf ^ 1];
     r.acc_rank = (uint32_t *)a.skeys[c->sorted_buf ^ 1];  // the spare key buffer holds 2 x 32 bits per item: the accepted items' ranks and cand
     r.cand = r.acc_rank + c->surv_item_cap;
+    r.acc_idx = r.cand;
     r.blk_base = c->d_blk_base;
     r.blk_counts = c->d_blk_counts;
     r.blk_start = c->d_blk_start;

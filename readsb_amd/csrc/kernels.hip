@@ -1436,9 +1436,13 @@ __global__ __launch_bounds__(kThreads) void k_replay_reset(const ReplayArgs r, u
 __global__ __launch_bounds__(kThreads) void k_replay_list(const ReplayArgs r, uint32_t *counters) {
     const uint32_t n_items = items_of(r);
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_items; i += gridDim.x * kThreads) {
-        const uint32_t info = r.info[i];
-        if (!combo_adds(item_combo(info)) || r.acc[i] == 0) continue;
-        const uint32_t v = item_value(info), g1 = (uint32_t)(r.keys[i] >> 3) + 1;
+        if (r.acc[i] == 0) continue;
+        const uint32_t info = r.info[i], g = (uint32_t)(r.keys[i] >> 3);
+        // message number -> item (k_replay_emit works message by message): accepted messages before the item's block + its rank there
+        const uint32_t place = r.blk_base[g / kBlock] + r.acc_rank[i];
+        if (place < n_items) r.acc_idx[place] = i;
+        if (!combo_adds(item_combo(info))) continue;
+        const uint32_t v = item_value(info), g1 = g + 1;
         if (r.t_cur[v] == g1) {
             const uint32_t slot = atomicAdd(&counters[kCntNewAdders], 1u);
             if (slot < r.new_adders_cap) r.new_adders[slot] = make_uint2(g1, v);
@@ -1506,32 +1510,25 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
-    // The wavefront walks the sorted item list 64 items at a time; the accepted ones among them (nearly all) are consecutive
-    // messages of the output: place = accepted messages before the item's 131072-sample block + its rank within the block.
-    const uint32_t n_items = items_of(r);
-    const uint32_t out_cap = r.host_out ? min(r.out_cap, r.host_cap) : r.out_cap;
+    uint32_t nacc = r.counters[kCntAccepted];
+    if (nacc > r.out_cap) nacc = r.out_cap;
+    if (r.host_out && nacc > r.host_cap) nacc = r.host_cap;
     uint32_t by_errors[3] = {0, 0, 0};  // wave-uniform
     constexpr int kRawVecs = (FMT == kFmtUC8 || FMT == kFmtMag16) ? 1 : 2;
     constexpr int kBps = 2 * kRawVecs;
     const uint32_t nthreads = gridDim.x * kT;
-    for (uint32_t base = (blockIdx.x * kT + threadIdx.x) & ~63u; base < n_items; base += nthreads) {
+    for (uint32_t base = (blockIdx.x * kT + threadIdx.x) & ~63u; base < nacc; base += nthreads) {
         const uint32_t mi = base + lane;
-        uint32_t g = 0, phase = 0, info = kComboDf17 << 27, score = 0, place = 0;
-        bool valid = false;
-        if (mi < n_items) {
-            const uint32_t acc = r.acc[mi];
-            if (acc) {
-                const uint64_t key = r.keys[mi];
-                g = (uint32_t)(key >> 3);
-                phase = (uint32_t)key & 7u;
-                info = r.info[mi];
-                score = acc - 1;
-                place = r.blk_base[g / kBlock] + r.acc_rank[mi];
-                valid = place < out_cap;
-            }
+        const bool valid = mi < nacc;
+        uint32_t g = 0, phase = 0, info = kComboDf17 << 27, score = 0;
+        if (valid) {
+            const uint32_t idx = r.acc_idx[mi];  // k_replay_list: message number -> item
+            const uint64_t key = r.keys[idx];
+            g = (uint32_t)(key >> 3);
+            phase = (uint32_t)key & 7u;
+            info = r.info[idx];
+            score = r.acc[idx] - 1;
         }
-        const uint64_t vm = __ballot(valid);
-        if (!vm) continue;  // wave-uniform
         const uint32_t combo = item_combo(info);
         const bool lng = !combo_is_short(combo);
         const uint32_t nbits = lng ? 112 : 56;
@@ -1656,7 +1653,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
             const bool df11 = combo >= kComboDf11Iid0 && combo <= kComboDf11IidX + 1;
             const double signal_power = (double)pw / 65535.0 / 65535.0;
             const double level = signal_power / (double)signal_len;
-            uint32_t *o = &sh.rec[threadIdx.x >> 6][lanes_below(vm) * 14];  // rsb_message, packed: 14 dwords; the wavefront's records in output order
+            uint32_t *o = &sh.rec[threadIdx.x >> 6][lane * 14];  // rsb_message, packed: 14 dwords
             o[0] = (uint32_t)ts;
             o[1] = (uint32_t)(ts >> 32);
             o[2] = __builtin_bswap32(w[0]);  // msg[0..3]
@@ -1674,13 +1671,12 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
             o[13] = (uint32_t)(lv >> 32);
         }
         {
-            // The wavefront's nv records are consecutive in the list, from the place of its first accepted item on: contiguous
-            // 16-byte stores where the run is whole and aligned (what makes writing straight into pinned host memory run at PCIe
-            // rate), dword stores otherwise.
+            // The wavefront's records [base, base + nv) are contiguous in the list: 3584 bytes as 224 x 16-byte stores, each
+            // instruction covering 1 KB without holes.  That is what makes writing straight into the caller's pinned host
+            // buffer (r.host_out: no device -> host copy afterwards) run at PCIe rate; dword stores at a 56-byte stride do not.
             wave_sync();
-            const uint32_t nv = (uint32_t)__popcll(vm);
-            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)place, (int)__builtin_ctzll(vm));
-            rsb_message *dst = (r.host_out ? r.host_out : r.out) + first;
+            const uint32_t nv = min(64u, nacc - base);
+            rsb_message *dst = (r.host_out ? r.host_out : r.out) + base;
             const uint32_t *src = sh.rec[threadIdx.x >> 6];
             if (nv == 64 && ((uintptr_t)dst & 15u) == 0) {
 #pragma unroll

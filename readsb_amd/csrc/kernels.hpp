@@ -107,6 +107,7 @@ struct ReplayArgs {
     uint32_t *cand;          // per item: k_replay_score's verdict for the offset that starts there (scratch)
     uint32_t *acc_rank;      // per accepted item: its rank among the accepted messages of its 131072-sample block (k_replay_walk)
     uint32_t *blk_base;      // accepted messages before every block, nblocks + 1 entries (k_replay_blkbase)
+    uint32_t *acc_idx;       // message number -> item (k_replay_list; takes cand's place: the walk is done with it by then)
     uint32_t *t_cur;         // 2^24 x u32: 0 = in the filter before this batch, g + 1 = first added by the message at
     uint32_t *t_next;        //             offset g of this batch, 0xffffffff = never
     uint32_t *blk_start;     // first item of every 131072-sample block, nblocks + 1 entries (launch_replay_bounds)
