@@ -145,8 +145,10 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=1 << 30, help="samples per GPU per step")
     ap.add_argument("--segment", type=int, default=1 << 23, help="synthetic segment that is tiled to --samples")
-    ap.add_argument("--batches", type=int, default=1, help="submit the recording as this many batches, two in flight (measured on MI355X: no gain -- the persistent "
-                    "scan kernel fills every CU's LDS, so the replay kernels of the previous batch cannot run beside it -- hence 1)")
+    ap.add_argument("--batches", type=int, default=1, help="submit the recording as this many batches")
+    ap.add_argument("--in-flight", type=int, default=3, help="batches submitted ahead of the one being collected (the library holds up to 4)")
+    ap.add_argument("--scan-workgroups", type=int, default=-1, help="rsb_config.scan_workgroups: CUs the persistent scan kernel takes; -1 = all with one batch, "
+                    "224 with several (one CU per shader engine stays free for the replay kernels of the batch before)")
     ap.add_argument("--output", choices=("records", "beast", "raw"), default="records",
                     help="what a step delivers to the host: rsb_message records (default, the metric's message list) or the Beast / raw "
                          "byte stream encoded on the device (rsb_collect_wire)")
@@ -201,8 +203,10 @@ def main() -> int:
     nb = max(1, args.batches)
     bs = -(-nc // nb) // 131072 * 131072 or nc
     cuts = list(range(0, nc, bs)) + [nc]
+    scan_wgs = args.scan_workgroups if args.scan_workgroups >= 0 else (0 if nb == 1 else 224)
     chans = [readsb_amd.Channel(fmt=args.format, fix_bits=args.fix_bits, mode_ac=args.modeac, dc_filter=args.dcfilter, device=local_rank,
-                                max_batch_samples=max(b - a for a, b in zip(cuts, cuts[1:])), queue_div=16 if args.dense else 32)
+                                max_batch_samples=max(b - a for a, b in zip(cuts, cuts[1:])), queue_div=16 if args.dense else 32,
+                                scan_workgroups=scan_wgs)
              for _ in range(C)]
     ch = chans[0]
     stream = torch.cuda.current_stream().cuda_stream
@@ -240,11 +244,13 @@ def main() -> int:
 
         if C == 1:
             ch.reset()
-            for k in range(len(cuts) - 1):
-                ch.submit(base + bps * cuts[k], cuts[k + 1] - cuts[k], stream)
-                if k >= 1:
-                    collect(ch)
-            collect(ch)
+            nbat, nxt, done = len(cuts) - 1, 0, 0
+            while done < nbat:  # up to args.in_flight batches submitted ahead of the one being collected
+                while nxt < nbat and nxt - done < args.in_flight:
+                    ch.submit(base + bps * cuts[nxt], cuts[nxt + 1] - cuts[nxt], stream)
+                    nxt += 1
+                collect(ch)
+                done += 1
             chan_msgs[1] = pos
         else:
             for i, c in enumerate(chans):
@@ -345,7 +351,7 @@ def main() -> int:
             "config": {"workload": workload,
                        "samples_per_gpu": n, "segment_samples": seg_n, "format": args.format, "fix_bits": args.fix_bits,
                        "mode_ac": bool(args.modeac), "dc_filter": bool(args.dcfilter),
-                       "batches_per_step": len(cuts) - 1, "batches_in_flight": 2 if len(cuts) > 2 else 1,
+                       "batches_per_step": len(cuts) - 1, "batches_in_flight": min(args.in_flight, len(cuts) - 1), "scan_workgroups": scan_wgs or "all",
                        "channels": world * C, "channels_per_gpu": C, "messages_per_step": nmsgs, "survivors_per_step": st["survivors"],
                        "full_size_check": parity, "oracle_check": oracle_check, "ranks_with_checks_ok": checks_ok, "output": args.output,
                        **({"wire_bytes_per_step": int(wire_bytes.size), "wire_check": wire_check} if wire_check else {})},

@@ -91,7 +91,7 @@ int setup_device(rsb_ctx *c) {
     if (c->cfg.scan_workgroups && (int)c->cfg.scan_workgroups < c->scan_grid) c->scan_grid = (int)c->cfg.scan_workgroups;
     if (c->scan_grid < 1) c->scan_grid = 1;
     // --dcfilter keeps one magnitude buffer, which the replay of a batch still reads: one batch in flight there
-    c->nslots = c->cfg.dc_filter ? 1 : 2;
+    c->nslots = c->cfg.dc_filter ? 1 : rsb_ctx::kMaxSlots;
     for (int k = 0; k < c->nslots; ++k) {
         rsb_slot &b = c->slots[k];
         HIP_TRY(c, hipMalloc((void **)&b.d_items, (size_t)c->item_cap * sizeof(ItemRec)));
@@ -107,8 +107,10 @@ int setup_device(rsb_ctx *c) {
         HIP_TRY(c, hipMalloc((void **)&b.d_block_sums, c->nblocks_cap * 2 * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&b.d_block_means, c->nblocks_cap * 2 * sizeof(double)));
         for (hipEvent_t &ev : b.ev) HIP_TRY(c, hipEventCreate(&ev));
+        for (hipEvent_t &ev : b.rev) HIP_TRY(c, hipEventCreate(&ev));
     }
     HIP_TRY(c, hipStreamCreateWithFlags(&c->replay_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (void *&p : c->d_carry) HIP_TRY(c, hipMalloc(&p, kTrailing * 4));
     c->sort_temp_bytes = sort_temp_bytes(c->surv_item_cap);
     HIP_TRY(c, hipMalloc(&c->d_sort_temp, c->sort_temp_bytes));
@@ -126,16 +128,19 @@ int setup_device(rsb_ctx *c) {
     c->host_replay_only = (c->cfg.flags & (RSB_FLAG_HOST_REPLAY | RSB_FLAG_EXACT_STATS)) != 0;
     if (!c->host_replay_only) {
         for (int w = 0; w < 2; ++w) HIP_TRY(c, hipMalloc((void **)&c->d_first_add[w], sizeof(uint32_t) << 24));
-        HIP_TRY(c, hipMalloc((void **)&c->d_blk_counts, c->nblocks_cap * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc((void **)&c->d_blk_start, (c->nblocks_cap + 1) * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc((void **)&c->d_blk_base, (c->nblocks_cap + 1) * sizeof(uint32_t)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_pin, (1 + kCntCount + c->nblocks_cap + 2 * rsb_ctx::kPinAdders) * sizeof(uint32_t), hipHostMallocDefault));
-        HIP_TRY(c, hipMalloc((void **)&c->d_new_adders, rsb_ctx::kNewAddersCap * sizeof(uint2)));
-        HIP_TRY(c, hipMalloc((void **)&c->d_addr_upload, 8 * IcaoFilter::kSlots * sizeof(uint32_t)));  // 2 x kSlots members, up to 6 x kSlots stale entries
-        // the message records of the device replay reuse the candidate records' memory (one path runs per batch)
+        // the message records of the device replay: as many as the candidate records' memory would hold
         c->out_cap = (uint32_t)((size_t)c->surv_cap * sizeof(Survivor) / sizeof(rsb_message));
+        for (int k = 0; k < c->nslots; ++k) {
+            rsb_slot &b = c->slots[k];
+            HIP_TRY(c, hipMalloc((void **)&b.d_out, (size_t)c->out_cap * sizeof(rsb_message)));
+            HIP_TRY(c, hipMalloc((void **)&b.d_blk_counts, c->nblocks_cap * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&b.d_blk_start, (c->nblocks_cap + 1) * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&b.d_blk_base, (c->nblocks_cap + 1) * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&b.d_new_adders, rsb_ctx::kNewAddersCap * sizeof(uint2)));
+            HIP_TRY(c, hipHostMalloc((void **)&b.h_pin, (1 + kCntCount + c->nblocks_cap + 2 * rsb_ctx::kPinAdders) * sizeof(uint32_t), hipHostMallocDefault));
+        }
+        HIP_TRY(c, hipMalloc((void **)&c->d_addr_upload, 8 * IcaoFilter::kSlots * sizeof(uint32_t)));  // 2 x kSlots members, up to 6 x kSlots stale entries
     }
-    for (hipEvent_t &ev : c->ev) HIP_TRY(c, hipEventCreate(&ev));
     return RSB_OK;
 }
 
@@ -177,18 +182,45 @@ bool emit_direct_enabled() {
     return on;
 }
 
-// Returns 1 when the batch was replayed on the device (messages in c->d_surv as rsb_message records,
-// counters in cnt), 0 when the host path has to take it, < 0 on error.
-// direct_out (optional): the caller's record buffer.  If the device can address it (pinned host memory), the emit kernel
-// writes the records there itself (*direct = 1) and no device -> host copy follows.
-// n_items: the number of kept items, or -- count_on_device -- the host's bound on it (the kernels then read the count the prune left in
-// the batch's counters; cnt[] is filled from the device together with the first round's results, and the caller checks it afterwards).
-int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_device, hipStream_t s, uint32_t cnt[kCntCount], rsb_message *direct_out = nullptr,
-                  size_t direct_cap = 0, int *direct = nullptr) {
+// The filter-superset prune of a scanned batch.  Normally the ordered compaction (the scan's item regions are sorted runs in
+// stream order: no sort needed afterwards); the atomic prune + radix sort remain for batches with marker items (exact
+// statistics) and are fallen back to at collect time when a scan wavefront overflowed one of its LDS queues (then some items
+// sit in the shared region, out of order).
+bool prune_is_ordered(const rsb_ctx *c, const BatchArgs &a) { return !a.emit_dead && !c->force_sort; }
+
+int enqueue_prune(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, hipStream_t s) {
+    b.pruned = true;
+    b.pruned_in_order = prune_is_ordered(c, a);
+    if (b.pruned_in_order)
+        HIP_TRY(c, launch_prune_ordered(a, s));
+    else
+        HIP_TRY(c, launch_prune(a, s));
+    return RSB_OK;
+}
+
+// ---- the sequential half on the device, in two steps so that the chain of batch k + 1 can be put on the replay stream while the
+// host still waits for batch k's records to leave (collect_ahead).
+
+// the readbacks of one replay round's results into the slot's pinned block: [changed | counters | block counts | first new adders]
+int enqueue_readbacks(rsb_ctx *c, rsb_slot &b, const ReplayArgs &r, hipStream_t s) {
+    uint32_t *pin = b.h_pin;
+    HIP_TRY(c, hipMemcpyAsync(pin + 1, b.d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(pin + 1 + kCntCount, b.d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(pin + 1 + kCntCount + c->nblocks_cap, b.d_new_adders, rsb_ctx::kPinAdders * sizeof(uint2), hipMemcpyDeviceToHost, s));
+    return RSB_OK;
+}
+
+// Step 1: everything of the first round -- table mirror if needed, block bounds, optimistic seed, score / walk / adds / compare,
+// the places of the accepted messages, their records, the readbacks -- goes onto stream s; nothing is waited for.
+// n_items: the number of kept items, or -- count_on_device -- the host's bound on it (the kernels then read the count the prune
+// left in the batch's counters, and replay_finish checks what the host could not know beforehand).
+// direct_out (optional, RSB_EMIT_DIRECT=1): the caller's record buffer.  If the device can address it (pinned host memory), the
+// emit kernel writes the records there itself and no device -> host copy follows.
+int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_device, hipStream_t s, rsb_message *direct_out = nullptr, size_t direct_cap = 0) {
     const BatchArgs &a = b.pending_args;
     int rc;
     if (c->filter_dirty && (rc = mirror_filter(c, s)) != RSB_OK) return rc;
-    ReplayArgs r;
+    ReplayArgs &r = b.chain_r;
     std::memset(&r, 0, sizeof(r));
     r.keys = a.skeys[c->sorted_buf];
     r.info = a.sinfo[c->sorted_buf];
@@ -200,28 +232,31 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devic
     r.acc_rank = (uint32_t *)a.skeys[c->sorted_buf ^ 1];  // the spare key buffer holds 2 x 32 bits per item: the accepted items' ranks and cand
     r.cand = r.acc_rank + c->surv_item_cap;
     r.acc_idx = r.cand;
-    r.blk_base = c->d_blk_base;
-    r.blk_counts = c->d_blk_counts;
-    r.blk_start = c->d_blk_start;
+    r.blk_base = b.d_blk_base;
+    r.blk_counts = b.d_blk_counts;
+    r.blk_start = b.d_blk_start;
     r.nblocks = (uint32_t)((b.pending_n + kBlock - 1) / kBlock);
-    r.new_adders = c->d_new_adders;
+    r.new_adders = b.d_new_adders;
     r.new_adders_cap = rsb_ctx::kNewAddersCap;
-    r.out = (rsb_message *)c->d_surv;
+    r.out = b.d_out;
     r.out_cap = c->out_cap;
     r.g0 = b.g0;
-    c->timing.replay_iterations = 0;
-    std::memset(cnt + kCntChanged, 0, (kCntCount - kCntChanged) * sizeof(uint32_t));
-    if (r.nblocks == 0) return 1;
-    r.t_cur = c->d_first_add[c->first_cur];  // seeded with the optimistic "first added at" entries (k_replay_seed)
+    b.chain_enqueued = true;
+    b.chain_count_on_device = count_on_device;
+    b.chain_to_host = false;
+    HIP_TRY(c, hipEventRecord(b.rev[1], s));
+    if (r.nblocks == 0) {
+        HIP_TRY(c, hipEventRecord(b.rev[2], s));
+        return RSB_OK;
+    }
+    r.t_cur = c->d_first_add[c->first_cur];  // seeded with the optimistic "first added at" entries (k_replay_table_min<true>)
     r.t_next = c->d_first_add[c->first_cur ^ 1];
     HIP_TRY(c, launch_replay_bounds(r, s));
     // Records straight into the caller's buffer when that is pinned host memory the device can address (hipHostMalloc /
     // hipHostRegister, e.g. torch's pin_memory): the emit kernel's stores then are the device -> host transfer.
-    bool to_host = false;
-    r.host_out = nullptr;
     // (measured on MI355X: a DMA copy of the finished list moves 41 MB at 56 GB/s beside a running scan kernel without slowing it,
     // the kernel's own stores over PCIe reach 50 GB/s and hold CUs meanwhile -- so the direct path is opt-in: RSB_EMIT_DIRECT=1)
-    if (emit_direct_enabled() && direct_out && direct && direct_cap) {
+    if (emit_direct_enabled() && direct_out && direct_cap) {
         const uint32_t hcap = (uint32_t)(direct_cap < 0xffffffffull ? direct_cap : 0xffffffffull);
         hipPointerAttribute_t lo_attr, hi_attr;
         const bool lo_ok = hipPointerGetAttributes(&lo_attr, direct_out) == hipSuccess && lo_attr.type == hipMemoryTypeHost && lo_attr.devicePointer;
@@ -231,38 +266,53 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devic
         if (hi_ok && (const char *)hi_attr.devicePointer - (const char *)lo_attr.devicePointer == (ptrdiff_t)((size_t)hcap * sizeof(rsb_message) - 1)) {
             r.host_out = (rsb_message *)lo_attr.devicePointer;
             r.host_cap = hcap;
-            to_host = true;
+            b.chain_to_host = true;
         }
     }
     // The first round is followed at once by the list and the records (the optimistic start is nearly always the fixed
     // point): one wait for "did the table move" and the counters together.  If it did move, those records are discarded,
     // the iteration goes on and they are written again.
+    HIP_TRY(c, launch_replay_iteration(a, r, s));
+    b.h_pin[0] = 0;
+    HIP_TRY(c, hipMemcpyAsync(&b.h_pin[0], b.d_counters + kCntChanged, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, launch_replay_select(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
+    HIP_TRY(c, launch_replay_emit(a, r, s));
+    if ((rc = enqueue_readbacks(c, b, r, s)) != RSB_OK) return rc;
+    HIP_TRY(c, hipEventRecord(b.rev[2], s));
+    return RSB_OK;
+}
+
+// Step 2: wait for the chain, look at what came back, go on iterating in the rare case that the optimistic table was not the
+// fixed point, fold the batch's new members into the tables and the host's filter.
+// Returns 1 when the batch was replayed on the device (messages in b.d_out as rsb_message records, counters in cnt), 0 when the
+// host path has to take it, -1000 when the chain ran on a count the host must not trust (cnt[] says why), < 0 on error.
+int replay_finish(rsb_ctx *c, rsb_slot &b, hipStream_t s, uint32_t cnt[kCntCount], int *direct = nullptr) {
+    const BatchArgs &a = b.pending_args;
+    ReplayArgs &r = b.chain_r;
+    b.chain_enqueued = false;
+    c->timing.replay_iterations = 0;
+    std::memset(cnt + kCntChanged, 0, (kCntCount - kCntChanged) * sizeof(uint32_t));
+    if (r.nblocks == 0) return 1;
+    uint32_t *pin = b.h_pin;
     bool converged = false, emitted = false;
     for (int it = 0; it < kMaxReplayIterations && !converged; ++it) {
-        r.t_cur = c->d_first_add[c->first_cur];
-        r.t_next = c->d_first_add[c->first_cur ^ 1];
-        HIP_TRY(c, launch_replay_iteration(a, r, s));
-        // what the host reads back lands in pinned memory (one wait, no staging copies): [changed | counters | block counts | new adders]
-        uint32_t *pin = c->h_pin;
-        uint32_t &changed = pin[0];
-        changed = 0;
-        HIP_TRY(c, hipMemcpyAsync(&pin[0], b.d_counters + kCntChanged, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        if (it == 0) {
-            HIP_TRY(c, launch_replay_select(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
-            HIP_TRY(c, launch_replay_emit(a, r, s));
-            HIP_TRY(c, hipMemcpyAsync(pin + 1, b.d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipMemcpyAsync(pin + 1 + kCntCount, c->d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipMemcpyAsync(pin + 1 + kCntCount + c->nblocks_cap, c->d_new_adders, rsb_ctx::kPinAdders * sizeof(uint2), hipMemcpyDeviceToHost, s));
+        if (it > 0) {
+            r.t_cur = c->d_first_add[c->first_cur];
+            r.t_next = c->d_first_add[c->first_cur ^ 1];
+            HIP_TRY(c, launch_replay_iteration(a, r, s));
+            pin[0] = 0;
+            HIP_TRY(c, hipMemcpyAsync(&pin[0], b.d_counters + kCntChanged, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         }
         HIP_TRY(c, hipStreamSynchronize(s));
+        const uint32_t changed = pin[0];
         if (it == 0) {
             std::memcpy(cnt, pin + 1, kCntCount * sizeof(uint32_t));
             std::memcpy(c->h_blk_counts.data(), pin + 1 + kCntCount, r.nblocks * sizeof(uint32_t));
-            if (count_on_device) {
+            if (b.chain_count_on_device) {
                 // now the host sees what the prune left: anything the kernels' clamps papered over ends the batch here
                 if (cnt[kCntOverflow] || cnt[kCntSurvItems] > c->surv_item_cap || cnt[kCntItems] != 0) {
                     c->filter_dirty = true;
-                    c->tables_valid = false;  // the rounds above ran on a list that does not count
+                    c->tables_valid = false;  // the round above ran on a list that does not count
                     return -1000;             // the caller looks at cnt[]
                 }
                 r.n_items = cnt[kCntSurvItems];  // exact from here on
@@ -285,18 +335,15 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devic
         return 0;
     }
     if (!emitted) {
-        uint32_t *pin = c->h_pin;
+        int rc;
         HIP_TRY(c, launch_replay_select(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
         HIP_TRY(c, launch_replay_emit(a, r, s));
-        HIP_TRY(c, hipMemcpyAsync(pin + 1, b.d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(pin + 1 + kCntCount, c->d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(pin + 1 + kCntCount + c->nblocks_cap, c->d_new_adders, rsb_ctx::kPinAdders * sizeof(uint2), hipMemcpyDeviceToHost, s));
+        if ((rc = enqueue_readbacks(c, b, r, s)) != RSB_OK) return rc;
         HIP_TRY(c, hipStreamSynchronize(s));
         std::memcpy(cnt, pin + 1, kCntCount * sizeof(uint32_t));
         std::memcpy(c->h_blk_counts.data(), pin + 1 + kCntCount, r.nblocks * sizeof(uint32_t));
     }
     HIP_TRY(c, launch_replay_fold(r, s));  // the batch's new members become "in the filter before the next batch" (asynchronous)
-    const bool parts_out = to_host && cnt[kCntAccepted] <= r.host_cap && cnt[kCntAccepted] <= r.out_cap;
     // The tables answer "is this address in the filter" as a set.  The reference's open-addressing table does
     // the same until it is full (icao_filter.c:76-79, 101-106): stay well clear of that, else replay on the host.
     const uint32_t nnew = cnt[kCntNewAdders];
@@ -305,16 +352,15 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devic
         c->tables_valid = false;  // entries folded to 0 that the host does not know of
         return 0;
     }
-    // with to_host the emit kernel has written the first min(accepted, host_cap) records into the caller's buffer: they are delivered
-    // (rsb_collect's contract for a short buffer: the first cap records and RSB_EOVERFLOW); nothing of this batch is in r.out then
-    (void)parts_out;
-    if (direct) *direct = to_host ? 1 : 0;
+    // with chain_to_host the emit kernel has written the first min(accepted, host_cap) records into the caller's buffer: they are
+    // delivered (rsb_collect's contract for a short buffer: the first cap records and RSB_EOVERFLOW); nothing of this batch is in r.out
+    if (direct) *direct = b.chain_to_host ? 1 : 0;
     if (nnew) {
         c->h_new_adders.resize(nnew);
         if (nnew <= rsb_ctx::kPinAdders)  // came along with the counters
-            std::memcpy(c->h_new_adders.data(), c->h_pin + 1 + kCntCount + c->nblocks_cap, nnew * sizeof(uint2));
+            std::memcpy(c->h_new_adders.data(), pin + 1 + kCntCount + c->nblocks_cap, nnew * sizeof(uint2));
         else
-            HIP_TRY(c, hipMemcpy(c->h_new_adders.data(), c->d_new_adders, nnew * sizeof(uint2), hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(c->h_new_adders.data(), b.d_new_adders, nnew * sizeof(uint2), hipMemcpyDeviceToHost));
         std::sort(c->h_new_adders.begin(), c->h_new_adders.end(), [](const uint2 &x, const uint2 &y) { return x.x < y.x; });
         for (const uint2 &e : c->h_new_adders) {
             c->replay.filter().add(e.y);  // in the order the reference learns them
@@ -322,6 +368,39 @@ int device_replay(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devic
         }
     }
     return 1;
+}
+
+// which batches need no word from the device before their replay chain is enqueued
+bool chain_needs_no_host(const rsb_ctx *c, const rsb_slot &b) {
+#ifdef RSB_STAGE_CLOCKS
+    return false;
+#else
+    const BatchArgs &a = b.pending_args;
+    return c->run_modes && !c->block_mode && (b.pruned ? b.pruned_in_order : prune_is_ordered(c, a)) && !c->host_replay_only && !c->defer_prune && !a.emit_dead &&
+           !a.keep_all && !emit_direct_enabled() &&
+           !(c->debug_flags & 256);
+#endif
+}
+
+uint32_t kept_items_bound(const rsb_ctx *c, const rsb_slot &b) {  // sizes the grids only: the kernels loop over whatever the count turns out to be
+    uint64_t bound = b.pending_n / 128;
+    if (bound < 4096) bound = 4096;
+    if (bound > c->surv_item_cap) bound = c->surv_item_cap;
+    return (uint32_t)bound;
+}
+
+// While the host waits for batch k's records to leave, the replay chain of the next scanned batch goes onto the replay stream
+// (its scan may still be running: the chain waits for its event).  Only when nothing forces the host to look first.
+void collect_ahead(rsb_ctx *c) {
+    if (!c->any_pending() || c->filter_dirty) return;
+    rsb_slot &nb = c->collect_slot();
+    if (!nb.pending || nb.chain_enqueued || !chain_needs_no_host(c, nb)) return;
+    hipStream_t s = c->replay_stream;
+    if (hipStreamWaitEvent(s, nb.ev[3], 0) != hipSuccess) return;
+    if (hipEventRecord(nb.rev[0], s) != hipSuccess) return;
+    if (!nb.pruned && enqueue_prune(c, nb, nb.pending_args, s) != RSB_OK) return;
+    c->sorted_buf = 0;
+    if (replay_enqueue(c, nb, kept_items_bound(c, nb), true, s) != RSB_OK) nb.chain_enqueued = false;  // collect will try again and report
 }
 
 const CrcTables &tables_for(int fix_bits) {
@@ -361,23 +440,24 @@ void rsb_destroy(rsb_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
-                    c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_blk_counts, c->d_blk_start, c->d_blk_base, c->d_new_adders, c->d_addr_upload, c->d_means,
+                    c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
                     c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge};
     for (rsb_slot &b : c->slots) {
-        void *sp[] = {b.d_items, b.d_region_counts, b.d_region_kept, b.d_region_masks, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
+        void *sp[] = {b.d_out, b.d_blk_counts, b.d_blk_start, b.d_blk_base, b.d_new_adders, b.d_items, b.d_region_counts, b.d_region_kept, b.d_region_masks, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
         for (void *p : sp)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : b.ev)
             if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : b.rev)
+            if (ev) (void)hipEventDestroy(ev);
+        if (b.h_pin) (void)hipHostFree(b.h_pin);
     }
     if (c->replay_stream) (void)hipStreamDestroy(c->replay_stream);
-    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (void *p : c->d_carry)
         if (p) (void)hipFree(p);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    for (hipEvent_t ev : c->ev)
-        if (ev) (void)hipEventDestroy(ev);
     delete c;
 }
 
@@ -390,7 +470,10 @@ int rsb_reset(rsb_ctx *c) {
     c->replay.reset();
     c->stream_pos = c->submit_pos = 0;
     c->submitted = c->collected = 0;
-    for (rsb_slot &b : c->slots) b.pending = false;
+    for (rsb_slot &b : c->slots) {
+        b.pending = false;
+        b.chain_enqueued = false;
+    }
     for (int &v : c->carry_valid) v = 0;
     c->finished = c->submit_finished = false;
     c->last_n = 0;
@@ -463,7 +546,7 @@ int rsb_seek(rsb_ctx *c, uint64_t stream_pos, const void *carry, int carry_on_de
         return RSB_EINVAL;
     }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const unsigned bps = (c->cfg.input_format == RSB_UC8) ? 2 : 4, k = c->submitted % 3;
+    const unsigned bps = (c->cfg.input_format == RSB_UC8) ? 2 : 4, k = c->submitted % rsb_ctx::kCarries;
     if (carry) HIP_TRY(c, hipMemcpy(c->d_carry[k], carry, (size_t)kTrailing * bps, carry_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     c->carry_valid[k] = carry ? 1 : 0;
     c->stream_pos = c->submit_pos = stream_pos;
@@ -513,30 +596,17 @@ int rsb_filter_export(rsb_ctx *c, uint32_t *out, size_t cap, size_t *n_out) {
     return RSB_OK;
 }
 
-// The filter-superset prune of a scanned batch.  Normally the ordered compaction (the scan's item regions are sorted runs in
-// stream order: no sort needed afterwards); the atomic prune + radix sort remain for batches with marker items (exact
-// statistics) and are fallen back to at collect time when a scan wavefront overflowed one of its LDS queues (then some items
-// sit in the shared region, out of order).
-static int enqueue_prune(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, hipStream_t s) {
-    b.pruned_in_order = !a.emit_dead && !c->force_sort;
-    if (b.pruned_in_order)
-        HIP_TRY(c, launch_prune_ordered(a, s));
-    else
-        HIP_TRY(c, launch_prune(a, s));
-    return RSB_OK;
-}
-
 static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
     HIP_TRY(c, hipMemsetAsync(b.d_counters, 0, kCntAlloc * sizeof(uint32_t), s));
     HIP_TRY(c, hipMemsetAsync(b.d_region_counts, 0, (size_t)a.n_regions * sizeof(uint32_t), s));
     HIP_TRY(c, hipEventRecord(b.ev[0], s));
     if (c->run_modes) HIP_TRY(c, launch_scan(a, c->scan_grid, s));
     HIP_TRY(c, hipEventRecord(b.ev[1], s));
+    // The prune runs at the head of the batch's replay chain, on the context's own stream (rsb_collect, or collect_ahead while
+    // the batch before is being delivered), not here: the caller's stream then carries the scans of successive batches back to
+    // back, and the prune sees whatever the caller has added to the superset in between (RSB_FLAG_DEFER_PRUNE relies on that).
+    b.pruned = false;
     b.pruned_in_order = false;
-    if (c->run_modes && !c->defer_prune) {
-        const int rc = enqueue_prune(c, b, a, s);
-        if (rc != RSB_OK) return rc;
-    }
     HIP_TRY(c, hipEventRecord(b.ev[2], s));
     b.means_on_device = nullptr;
     if ((c->run_ac || c->exact_stats) && nsamples) {
@@ -559,7 +629,7 @@ static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t n
     if (!c->block_mode && nsamples % kBlock == 0 && nsamples) {
         // the next batch's 326-sample overlap (sdr_ifile.c:199-201)
         const unsigned bps = (a.fmt == kFmtUC8 || a.fmt == kFmtMag16) ? 2 : 4;
-        const unsigned k = (c->submitted + 1) % 3;
+        const unsigned k = (c->submitted + 1) % rsb_ctx::kCarries;
         HIP_TRY(c, hipMemcpyAsync(c->d_carry[k], (const char *)a.iq + (nsamples - kTrailing) * bps, (size_t)kTrailing * bps, hipMemcpyDeviceToDevice, s));
         c->carry_valid[k] = 1;
     }
@@ -582,7 +652,7 @@ static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t n
 int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) {
     if (!c || (!iq_dev && nsamples) || c->block_mode) return RSB_EINVAL;
     if (c->submitted - c->collected >= (unsigned)c->nslots) {
-        c->err = c->nslots == 1 ? "rsb_submit: previous batch not collected" : "rsb_submit: two batches already in flight: collect one first";
+        c->err = c->nslots == 1 ? "rsb_submit: previous batch not collected" : "rsb_submit: four batches already in flight: collect one first";
         return RSB_ESTATE;
     }
     if (c->submit_finished || c->submit_pos % kBlock != 0) {
@@ -685,7 +755,7 @@ int device_merge_modeac(rsb_ctx *c, rsb_slot &b, uint32_t nacc, size_t nblocks, 
     }
     HIP_TRY(c, hipMemcpyAsync(c->d_merge, c->h_merge.data(), bytes, hipMemcpyHostToDevice, s));
     MergeArgs m;
-    m.modes = (const rsb_message *)c->d_surv;
+    m.modes = b.d_out;
     m.n_modes = nacc;
     m.blk_first = (const uint32_t *)c->d_merge;
     m.ac_before = m.blk_first + nblocks + 1;
@@ -715,7 +785,8 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     // everything from here on runs on the context's own stream, behind this batch's scan and beside the next batch's
     hipStream_t s = c->replay_stream;
     HIP_TRY(c, hipStreamWaitEvent(s, b.ev[3], 0));
-    if (c->defer_prune && c->run_modes) {  // against the superset as the caller has widened it
+    if (!b.chain_enqueued) HIP_TRY(c, hipEventRecord(b.rev[0], s));  // (collect_ahead has recorded it otherwise)
+    if (c->run_modes && !b.pruned && !b.chain_enqueued) {  // against the superset as it is now (the caller may have widened it)
         const int rc = enqueue_prune(c, b, b.pending_args, s);
         if (rc != RSB_OK) return rc;
     }
@@ -730,16 +801,15 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     // order and their number in the counters, the replay kernels read it there, and the host waits ONCE, for the first
     // round's results and the counters together.  Anything unusual (a scan wavefront overflowed an LDS queue, a device queue
     // is full, marker items, host replay, records written straight to the caller's buffer) takes the step-by-step path below.
-    bool replayed = false;
-#ifndef RSB_STAGE_CLOCKS
-    if (c->run_modes && b.pruned_in_order && !c->host_replay_only && !a.emit_dead && !a.keep_all && !emit_direct_enabled() && !(c->debug_flags & 256)) {
-        HIP_TRY(c, hipEventRecord(c->ev[0], s));
-        HIP_TRY(c, hipEventRecord(c->ev[1], s));
-        c->sorted_buf = 0;
-        uint64_t bound = b.pending_n / 128;
-        if (bound < 4096) bound = 4096;
-        if (bound > c->surv_item_cap) bound = c->surv_item_cap;
-        on_device = device_replay(c, b, (uint32_t)bound, true, s, cnt);
+    bool replayed = false, chain_ran = false;
+    if (b.chain_enqueued || chain_needs_no_host(c, b)) {
+        chain_ran = true;
+        if (!b.chain_enqueued) {
+            c->sorted_buf = 0;
+            const int rc = replay_enqueue(c, b, kept_items_bound(c, b), true, s);
+            if (rc != RSB_OK) return rc;
+        }
+        on_device = replay_finish(c, b, s, cnt);
         if (on_device == -1000)
             on_device = 0;  // cnt[] says why: looked at below
         else if (on_device < 0)
@@ -747,7 +817,6 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         else
             replayed = true;
     }
-#endif
     if (!replayed && !(cnt[kCntOverflow] | cnt[kCntItems] | cnt[kCntSurvItems])) {
         HIP_TRY(c, hipMemcpyAsync(cnt, b.d_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
@@ -776,7 +845,6 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     }
     uint32_t n_items = cnt[kCntSurvItems];
     if (!replayed) {
-        HIP_TRY(c, hipEventRecord(c->ev[0], s));
         if (b.pruned_in_order && cnt[kCntItems] != 0 && c->run_modes) {
             // a scan wavefront overflowed an LDS queue: its per-thread path put items into the shared region, out of order.  Prune once
             // more, this time with the sort behind it.
@@ -798,7 +866,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
             c->sorted_buf = 0;  // packed in stream order by the prune itself
         else
             HIP_TRY(c, launch_sort(a, n_items, c->d_sort_temp, c->sort_temp_bytes, &c->sorted_buf, s));
-        HIP_TRY(c, hipEventRecord(c->ev[1], s));
+        HIP_TRY(c, hipEventRecord(b.rev[1], s));
 
         // the sequential half: on the device, unless asked otherwise or the device path declines the batch
         if (!c->run_modes) {
@@ -808,7 +876,10 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         } else if (!c->host_replay_only && !a.emit_dead && !a.keep_all) {
             // records wanted and nothing to interleave: the list can leave in parts while it is still being written
             const bool parts_ok = !wire && out && cnt[kCntAc] == 0;
-            on_device = device_replay(c, b, n_items, false, s, cnt, parts_ok ? out : nullptr, cap, &direct_parts);
+            int rc = replay_enqueue(c, b, n_items, false, s, parts_ok ? out : nullptr, cap);
+            chain_ran = true;
+            if (rc != RSB_OK) return rc;
+            on_device = replay_finish(c, b, s, cnt, &direct_parts);
             if (on_device < 0) return on_device;
             if (!on_device) direct_parts = 0;  // (whatever the kernel wrote to the buffer, the host path rewrites it)
         }
@@ -819,7 +890,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         HIP_TRY(c, launch_unique_finalize(a, n_items, c->sorted_buf, c->d_sort_temp, c->sort_temp_bytes, s));
         HIP_TRY(c, hipMemcpyAsync(&nsurv, b.d_counters + kCntSurvivors, sizeof(nsurv), hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    if (!on_device || !chain_ran) HIP_TRY(c, hipEventRecord(b.rev[2], s));  // (the device replay's chain records it behind its emit kernel)
     HIP_TRY(c, hipStreamSynchronize(s));
     if (!on_device && nsurv > c->surv_cap) {
         char buf[200];
@@ -847,7 +918,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     rsb_stats &st = c->replay.stats();
     if (on_device) {
         const uint32_t nacc = cnt[kCntAccepted];
-        const rsb_message *list = (const rsb_message *)c->d_surv;  // the batch's messages on the device
+        const rsb_message *list = b.d_out;  // the batch's messages on the device
         size_t nlist = nacc;
         bool on_dev_list = true;
         if (nac) {  // interleave the Mode A/C messages on the device as well
@@ -868,14 +939,18 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
             delivered = true;
         } else if (on_dev_list) {
             // straight into the caller's buffer
+            // straight into the caller's buffer, on the copy stream: everything the list depends on has been waited for, and the
+            // replay stream is free to take the next batch's chain meanwhile
             n = nlist;
             const size_t ncopy = n < cap ? n : cap;
-            if (ncopy) HIP_TRY(c, hipMemcpyAsync(out, list, ncopy * sizeof(rsb_message), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
+            if (list != b.d_out) HIP_TRY(c, hipStreamSynchronize(s));  // (a merged list: its kernel ran on the replay stream)
+            if (ncopy) HIP_TRY(c, hipMemcpyAsync(out, list, ncopy * sizeof(rsb_message), hipMemcpyDeviceToHost, c->copy_stream));
+            collect_ahead(c);
+            HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
             delivered = true;
         } else {
             c->dev_msgs.resize(nacc);
-            if (nacc) HIP_TRY(c, hipMemcpyAsync(c->dev_msgs.data(), c->d_surv, (size_t)nacc * sizeof(rsb_message), hipMemcpyDeviceToHost, s));
+            if (nacc) HIP_TRY(c, hipMemcpyAsync(c->dev_msgs.data(), b.d_out, (size_t)nacc * sizeof(rsb_message), hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
         }
         for (int e = 0; e < 3; ++e) st.demod_accepted[e] += cnt[kCntAccE0 + e];
@@ -889,11 +964,12 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
 
     float ms = 0;
     (void)hipEventElapsedTime(&c->timing.scan_ms, b.ev[0], b.ev[1]);
-    (void)hipEventElapsedTime(&c->timing.prune_ms, b.ev[1], b.ev[2]);
+    c->timing.prune_ms = 0;
     (void)hipEventElapsedTime(&c->timing.modeac_ms, b.ev[2], b.ev[3]);
     (void)hipEventElapsedTime(&c->timing.total_ms, b.ev[0], b.ev[3]);
-    (void)hipEventElapsedTime(&c->timing.sort_ms, c->ev[0], c->ev[1]);
-    (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&c->timing.prune_ms, b.rev[0], b.rev[1]);  // prune (+ the radix sort in the fallback cases)
+    c->timing.sort_ms = 0;
+    (void)hipEventElapsedTime(&ms, b.rev[1], b.rev[2]);
     c->timing.device_replay_ms = on_device ? ms : 0.0f;
     if (!on_device) c->timing.prune_ms += ms;  // the candidate re-slice belongs to the prune stage of the host path
     c->timing.total_ms += c->timing.sort_ms + ms;

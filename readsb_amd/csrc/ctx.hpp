@@ -17,7 +17,8 @@ struct rsb_slot {
     uint32_t *d_region_counts = nullptr;
     uint32_t *d_region_kept = nullptr;
     uint64_t *d_region_masks = nullptr;
-    bool pruned_in_order = false;     // the pending batch went through launch_prune_ordered: its kept items need no sort
+    bool pruned = false;              // the filter-superset prune of the pending batch has been enqueued
+    bool pruned_in_order = false;     // ... as launch_prune_ordered: its kept items need no sort
     uint64_t *d_skeys[2] = {nullptr, nullptr};
     uint32_t *d_sinfo[2] = {nullptr, nullptr};
     rsb::AcCand *d_ac = nullptr;
@@ -25,6 +26,15 @@ struct rsb_slot {
     uint64_t *d_block_sums = nullptr;
     double *d_block_means = nullptr;  // SC16 / SC16Q11 with Mode A/C: the float converters' per-block means
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // scan start / end, prune end, Mode A/C end
+    hipEvent_t rev[3] = {nullptr, nullptr, nullptr};          // collect side: sort start / end, replay end
+    // device replay of this batch (one set per slot: the chain of batch k + 1 is enqueued while batch k's records still leave)
+    rsb_message *d_out = nullptr;     // the batch's message records
+    uint32_t *d_blk_counts = nullptr, *d_blk_start = nullptr, *d_blk_base = nullptr;
+    uint2 *d_new_adders = nullptr;
+    uint32_t *h_pin = nullptr;        // pinned: what the host reads back per batch (changed flag, counters, block counts, first new adders)
+    bool chain_enqueued = false;      // the first replay round, the records and the readbacks are on the replay stream already
+    bool chain_count_on_device = false, chain_to_host = false;
+    rsb::ReplayArgs chain_r;
     bool pending = false;
     const double *means_on_device = nullptr;  // per-block (mean_level, mean_power) of the pending batch, when taken from float means
     uint64_t pending_n = 0, g0 = 0;   // samples of the batch, its stream position
@@ -36,7 +46,6 @@ struct rsb_ctx {
     explicit rsb_ctx(const rsb_config &c) : cfg(c), replay(c.fix_bits) {
         run_ac = c.mode_ac != 0;
         std::memset(&timing, 0, sizeof(timing));
-        for (hipEvent_t &e : ev) e = nullptr;
     }
 
     rsb_config cfg;
@@ -81,10 +90,7 @@ struct rsb_ctx {
     bool exact_stats = false;       // RSB_FLAG_EXACT_STATS: every gated offset goes to the host replay, block means are kept
     std::vector<double> h_blk_mean_power;
     std::vector<uint64_t> h_blk_sums;
-    uint32_t *d_blk_counts = nullptr, *d_blk_start = nullptr, *d_blk_base = nullptr;
-    uint32_t *h_pin = nullptr;        // pinned: what the host reads back per batch (changed flag, counters, block counts, first new adders)
     static constexpr uint32_t kPinAdders = 1024;
-    uint2 *d_new_adders = nullptr;
     uint32_t *d_addr_upload = nullptr;
     uint32_t out_cap = 0;
     uint32_t *d_wire_off = nullptr;  // rsb_collect_wire: byte offset per message (grown on demand)
@@ -105,23 +111,25 @@ struct rsb_ctx {
     double *d_means = nullptr;
 
     // stream state
-    rsb_slot slots[2];
-    // the 326 samples before batch k (the tail of batch k - 1, input format) live in d_carry[k % 3]: written when batch k - 1 is
+    static constexpr int kMaxSlots = 4;
+    rsb_slot slots[kMaxSlots];
+    // the 326 samples before batch k (the tail of batch k - 1, input format) live in d_carry[k % (slots + 1)]: written when batch k - 1 is
     // submitted, read by the scan and the replay of batch k, free again once batch k is collected
-    void *d_carry[3] = {nullptr, nullptr, nullptr};
-    int carry_valid[3] = {0, 0, 0};
-    int nslots = 1;                   // 2 unless --dcfilter (one magnitude buffer) or block mode
+    static constexpr int kCarries = kMaxSlots + 1;
+    void *d_carry[kCarries] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int carry_valid[kCarries] = {0, 0, 0, 0, 0};
+    int nslots = 1;                   // kMaxSlots unless --dcfilter (one magnitude buffer)
     unsigned submitted = 0, collected = 0;  // batches so far: slot = count % nslots; submitted - collected <= nslots
     rsb_slot &submit_slot() { return slots[submitted % nslots]; }
     rsb_slot &collect_slot() { return slots[collected % nslots]; }
     bool any_pending() const { return submitted != collected; }
     uint64_t last_n = 0;              // samples of the last collected batch
+    hipStream_t copy_stream = nullptr;    // the finished record list leaves on this one (a DMA copy beside whatever the kernels do)
     hipStream_t replay_stream = nullptr;  // sort / replay / copy-out run here, behind the batch's scan (event) and beside the next one's
     uint64_t stream_pos = 0;          // of the next batch to collect
     uint64_t submit_pos = 0;          // of the next batch to submit
     bool finished = false, submit_finished = false;
 
-    hipEvent_t ev[4];                 // collect side: sort start / end, replay end
     rsb_timing timing;
     std::string err;
     std::vector<rsb::Survivor> h_surv;
@@ -136,8 +144,8 @@ struct rsb_ctx {
         rsb::BatchArgs a;
         std::memset(&a, 0, sizeof(a));
         a.iq = iq;
-        a.carry = carry ? carry : d_carry[submitted % 3];
-        a.carry_valid = carry ? 1 : carry_valid[submitted % 3];
+        a.carry = carry ? carry : d_carry[submitted % kCarries];
+        a.carry_valid = carry ? 1 : carry_valid[submitted % kCarries];
         a.fmt = fmt;
         a.n = n;
         a.tab.uc8_lut = d_lut;

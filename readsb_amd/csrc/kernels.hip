@@ -829,7 +829,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         // The gated offsets in ascending order (the edge queue is filled bit by bit, not offset by offset): rank by counting, the
         // queue is short (about 25 entries).  From here on everything keeps that order -- (offset, phase) pairs, the frame list,
         // the ballot compactions -- so the wavefront's items leave sorted by (offset, phase).
-        if (ngq > 1) {
+        if (ngq > 1 && !(a.debug_flags & 8)) {
             uint32_t mine[kGateCap / 64], rank[kGateCap / 64];
 #pragma unroll
             for (int h = 0; h < kGateCap / 64; ++h) {

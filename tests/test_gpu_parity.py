@@ -107,30 +107,32 @@ def _addresses(n, seed):
 
 @pytest.mark.parametrize("name", ["dense_fix1_ac", "mixed_fix1"])
 def test_two_batches_in_flight(name, built):
-    """rsb_submit of batch i + 1 before rsb_collect of batch i (the scan of one batch runs beside the replay and the copy-out
-    of the previous one): same message list as the one-shot run; a third submit is refused."""
+    """rsb_submit of later batches before rsb_collect of batch i (their scans run beside the replay and the copy-out of the
+    earlier ones; the replay chain of batch i + 1 is enqueued while batch i's records leave): same message list as the one-shot
+    run, with two and with four batches in flight; a fifth submit is refused."""
     import torch
 
     sc, kw = SCENARIOS[name]
     iq = generate(sc)
     want, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
     dev = torch.from_numpy(np.ascontiguousarray(iq).view(np.uint8).reshape(-1, 2)).cuda()
-    n, step = dev.shape[0], 5 * 131072
-    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=step)
-    cuts = list(range(0, n, step)) + [n]
-    parts = []
-    for k in range(len(cuts) - 1):
-        ch.submit(dev[cuts[k]:].data_ptr(), cuts[k + 1] - cuts[k], None)
-        if k == 1:
-            with pytest.raises(readsb_amd.RsbError):  # two in flight already
-                ch.submit(dev[cuts[2]:].data_ptr(), min(step, n - cuts[2]), None)
-        if k >= 1:
+    n = dev.shape[0]
+    for step, depth in ((5 * 131072, 2), (2 * 131072, 4), (3 * 131072, 3)):
+        ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=step)
+        cuts = list(range(0, n, step)) + [n]
+        nb, parts, nxt = len(cuts) - 1, [], 0
+        while len(parts) < nb:
+            while nxt < nb and nxt - len(parts) < depth:
+                ch.submit(dev[cuts[nxt]:].data_ptr(), cuts[nxt + 1] - cuts[nxt], None)
+                nxt += 1
+            if depth == 4 and nxt - len(parts) == 4 and nxt < nb:
+                with pytest.raises(readsb_amd.RsbError):  # four in flight already
+                    ch.submit(dev[cuts[nxt]:].data_ptr(), cuts[nxt + 1] - cuts[nxt], None)
             parts.append(ch.collect(cap=1 << 16).copy())
-    parts.append(ch.collect(cap=1 << 16).copy())
-    got = np.concatenate(parts)
-    assert first_mismatch(want, got.view(REC_DTYPE)) is None
-    assert ch.stats()["samples_processed"] == n
-    ch.close()
+        got = np.concatenate(parts)
+        assert first_mismatch(want, got.view(REC_DTYPE)) is None
+        assert ch.stats()["samples_processed"] == n
+        ch.close()
 
 
 def test_prefilled_filter(built):
