@@ -48,7 +48,8 @@ class Stats(C.Structure):
                 ("gated_offsets", C.c_uint64), ("live_candidates", C.c_uint64), ("survivors", C.c_uint64),
                 ("modeac_candidates", C.c_uint64),
                 ("signal_power_sum", C.c_double), ("signal_power_count", C.c_uint64), ("noise_power_sum", C.c_double),
-                ("noise_power_count", C.c_uint64), ("peak_signal_power", C.c_double), ("strong_signal_count", C.c_uint64)]
+                ("noise_power_count", C.c_uint64), ("peak_signal_power", C.c_double), ("strong_signal_count", C.c_uint64),
+                ("general_strips", C.c_uint64), ("patched_strips", C.c_uint64)]
 
 
 class Timing(C.Structure):

@@ -291,7 +291,7 @@ int replay_finish(rsb_ctx *c, rsb_slot &b, hipStream_t s, uint32_t cnt[kCntCount
     ReplayArgs &r = b.chain_r;
     b.chain_enqueued = false;
     c->timing.replay_iterations = 0;
-    std::memset(cnt + kCntChanged, 0, (kCntCount - kCntChanged) * sizeof(uint32_t));
+    std::memset(cnt + kCntChanged, 0, (kCntGeneralStrips - kCntChanged) * sizeof(uint32_t));  // the replay's own counters
     if (r.nblocks == 0) return 1;
     uint32_t *pin = b.h_pin;
     bool converged = false, emitted = false;
@@ -1005,6 +1005,9 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
 
     st.samples_processed += b.pending_n;
     st.gated_offsets += cnt[kCntGated];
+    st.general_strips += cnt[kCntGeneralStrips];
+    st.patched_strips += cnt[kCntFixedStrips];
+    if (std::getenv("RSB_VERBOSE")) std::fprintf(stderr, "readsb_amd: %u strips converted on the general path, %u patched from the full UC8 table, %u gated offsets\n", cnt[kCntGeneralStrips], cnt[kCntFixedStrips], cnt[kCntGated]);
     st.live_candidates += cnt[kCntItemsTotal];
     st.survivors += on_device ? cnt[kCntAccepted] : cnt[kCntSurvivors];
     st.modeac_candidates += cnt[kCntAc];

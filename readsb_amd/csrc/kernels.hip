@@ -426,8 +426,19 @@ struct __attribute__((aligned(16))) WaveShared {
 };
 static_assert(sizeof(WaveShared) % 16 == 0, "per-wave LDS regions must keep 16-byte alignment");
 
+// UC8 magnitudes by "radial" index.  convert.c:35-61 tabulates a function of (2 I - 255)^2 + (2 Q - 255)^2, and
+//   P(I, Q) = I (255 - I) + Q (255 - Q)  =  (130050 - that sum) / 4,  even, 0 .. 32512,
+// is ONE v_dot4_u32_u8 of the sample's two bytes with their complements: P is the byte offset of the sample's entry in a
+// table of uint16.  (The folded 128 x 128 table needed ~7 instructions per sample for its address.)  Small signals land
+// in a few neighbouring dwords: distinct banks or the same dword, both conflict-free.
+// The reference's float arithmetic breaks the "function of the sum" rule for a few (I, Q): two values of P hold two different
+// magnitudes each (60465/60466 and 49681/49682, 48 of the 65536 byte pairs).  The table build finds such entries by itself
+// and stores magnitude 0 there, which no sample has (the smallest is 363); a strip that reads one is redone on the general path.
+constexpr int kRadialEntries = 16264;  // P / 2 <= 16256, padded to a multiple of 8
+constexpr uint32_t kRadialSentinel = 0u ^ 0x8000u;  // magnitude 0, biased: the smallest int16
+
 struct __attribute__((aligned(16))) ScanShared {
-    uint16_t lut[16384];
+    uint16_t lut[kRadialEntries];
     uint32_t coef[10][16];           // [parity of e0 * 5 + trial phase - 4][3 v + dword]: negated tap pairs
     uint32_t bloom[2][kBloomWords];  // one bit per hashed syndrome of the 56- / 112-bit repair table: most lookups end here
     uint32_t gsyn[(12 + 23) * 32];   // per 5-bit group of a 56- / 112-bit frame: XOR of the single-bit syndromes of the set bits
@@ -469,6 +480,46 @@ __device__ __forceinline__ uint4 uc8_chunk(const uint4 x, const uint16_t *lut) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = *(const uint16_t *)(b + a[k]);  // all eight lookups in flight together
     return make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+}
+
+// 8 UC8 samples -> 8 biased magnitudes through the radial table (ScanShared::lut), in two halves so that the table reads of
+// one chunk fly while the previous chunk is worked on.  The reads are written out by hand to control exactly that; the
+// compiler does not count them in its s_waitcnt bookkeeping, so the waits are ours: LDS operations of a wavefront complete
+// in order, lgkmcnt(8) means "everything but the 8 most recent", i.e. the chunk issued before the latest one.
+// (ds_read_u16_d16_hi puts the second sample of a pair into the upper half of its register; whether it keeps or clears the
+// lower half depends on the SRAM-ECC mode, so the pair is joined with a v_perm that takes only the halves that were loaded.)
+struct RadialChunk {
+    uint32_t lo[4], hi[4];
+};
+__device__ __forceinline__ void radial_issue(const uint4 x, uint32_t lut_lds, RadialChunk &c) {  // lut_lds: LDS byte address of the table
+    const uint32_t X[4] = {x.x, x.y, x.z, x.w};
+    uint32_t P[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // P = I (255 - I) + Q (255 - Q) per sample; the table's address rides in the accumulator
+        const uint32_t nx = ~X[k];
+        P[2 * k] = __builtin_amdgcn_udot4(X[k] & 0x0000ffffu, nx, lut_lds, false);
+        P[2 * k + 1] = __builtin_amdgcn_udot4(X[k] & 0xffff0000u, nx, lut_lds, false);
+    }
+    asm volatile(
+        "ds_read_u16 %0, %8\n\tds_read_u16 %1, %9\n\tds_read_u16 %2, %10\n\tds_read_u16 %3, %11\n\t"
+        "ds_read_u16_d16_hi %4, %12\n\tds_read_u16_d16_hi %5, %13\n\tds_read_u16_d16_hi %6, %14\n\tds_read_u16_d16_hi %7, %15"
+        : "=&v"(c.lo[0]), "=&v"(c.lo[1]), "=&v"(c.lo[2]), "=&v"(c.lo[3]), "=&v"(c.hi[0]), "=&v"(c.hi[1]), "=&v"(c.hi[2]), "=&v"(c.hi[3])
+        : "v"(P[0]), "v"(P[2]), "v"(P[4]), "v"(P[6]), "v"(P[1]), "v"(P[3]), "v"(P[5]), "v"(P[7])
+        : "memory");
+}
+template <int NEWER>  // 8: one younger chunk is in flight; 0: none
+__device__ __forceinline__ uint4 radial_take(RadialChunk &c, uint32_t &mn) {
+    if constexpr (NEWER == 8)
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(c.lo[0]), "+v"(c.lo[1]), "+v"(c.lo[2]), "+v"(c.lo[3]), "+v"(c.hi[0]), "+v"(c.hi[1]), "+v"(c.hi[2]), "+v"(c.hi[3]) : : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c.lo[0]), "+v"(c.lo[1]), "+v"(c.lo[2]), "+v"(c.lo[3]), "+v"(c.hi[0]), "+v"(c.hi[1]), "+v"(c.hi[2]), "+v"(c.hi[3]) : : "memory");
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        o[k] = __builtin_amdgcn_perm(c.hi[k], c.lo[k], 0x07060100u);
+        mn = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(short2v, mn), __builtin_bit_cast(short2v, o[k])));
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 template <int FMT>
@@ -520,16 +571,17 @@ __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t x, uint32_t y) {  // v_p
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(short2v, x), __builtin_bit_cast(short2v, y)));
 }
 
-// The comparisons of one chunk (8 biased samples in p, the next chunk's first pair in nx) shifted into
-// the bit-sliced words: after the 8 passes of a strip, bits 8..15 of accL[i] hold m[s] < m[s+1] for
-// sample 2i of the lane's chunks (bit 8 + t = pass t), bits 24..31 the same for sample 2i + 1; accG: '>'.
-__device__ __forceinline__ void edge_accumulate(const uint4 &p, uint32_t nx, uint32_t (&accL)[4], uint32_t (&accG)[4]) {
+// The comparisons of one chunk (8 biased samples in p, the next chunk's first pair in nx) shifted into the bit-sliced
+// words: after the passes of a strip, byte 1 of acc[i] holds m[s] < m[s+1] for sample 2i of the lane's chunks (bit t of the
+// byte, counted from bit 8 - kPasses = pass t), byte 0 the same for '>', bytes 3 and 2 those of sample 2i + 1.
+__device__ __forceinline__ void edge_accumulate(const uint4 &p, uint32_t nx, uint32_t (&acc)[4]) {
     const uint32_t d[5] = {p.x, p.y, p.z, p.w, nx};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t n = __builtin_amdgcn_alignbit(d[i + 1], d[i], 16);  // samples 2i+1, 2i+2
-        accL[i] = (accL[i] >> 1) | (pk_sub_sat(d[i], n) & 0x80008000u);
-        accG[i] = (accG[i] >> 1) | (pk_sub_sat(n, d[i]) & 0x80008000u);
+        // v_pk_sub_i16 clamp: sign bits = '<' per half; the sign bytes of both differences side by side
+        const uint32_t z = __builtin_amdgcn_perm(pk_sub_sat(d[i], n), pk_sub_sat(n, d[i]), 0x07030501u);
+        acc[i] = ((acc[i] >> 1) & 0x7f7f7f7fu) | (z & 0x80808080u);
     }
 }
 
@@ -641,11 +693,20 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     ScanShared &sh = *reinterpret_cast<ScanShared *>(scan_lds);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform: SGPR
 
-    if (FMT == kFmtUC8)
+    if (FMT == kFmtUC8) {
+        // one quadrant of the byte pairs covers every P (the table is symmetric under v -> 255 - v, as the folded table assumed)
+        for (uint32_t i = tid; i < (uint32_t)kRadialEntries; i += kScanThreads) sh.lut[i] = (uint16_t)kRadialSentinel;
+        __syncthreads();
         for (uint32_t i = tid; i < 16384; i += kScanThreads) {
-            const uint32_t ai = i & 127, aq = i >> 7;
-            sh.lut[i ^ ((aq & 31) << 1)] = (uint16_t)(a.tab.uc8_lut[((128 + aq) << 8) | (128 + ai)] ^ kBias);
+            const uint32_t vi = 128 + (i & 127), vq = 128 + (i >> 7);
+            sh.lut[(vi * (255 - vi) + vq * (255 - vq)) >> 1] = (uint16_t)(a.tab.uc8_lut[(vq << 8) | vi] ^ kBias);
         }
+        __syncthreads();
+        for (uint32_t i = tid; i < 16384; i += kScanThreads) {  // byte pairs that share a P and not a magnitude: no entry for that P
+            const uint32_t vi = 128 + (i & 127), vq = 128 + (i >> 7), k = (vi * (255 - vi) + vq * (255 - vq)) >> 1;
+            if (sh.lut[k] != (uint16_t)(a.tab.uc8_lut[(vq << 8) | vi] ^ kBias)) sh.lut[k] = (uint16_t)kRadialSentinel;
+        }
+    }
     for (uint32_t i = tid; i < 2 * kBloomWords; i += kScanThreads) sh.bloom[0][i] = 0;
     for (uint32_t i = tid; i < 160; i += kScanThreads) {
         const uint32_t row = i >> 4, e = i & 15;
@@ -676,7 +737,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     WaveShared &W = sh.w[wave];
     const uint32_t gwave = blockIdx.x * kScanWaves + wave;
     ItemRec *region = a.items + (size_t)gwave * a.item_region;
-    uint32_t nitems = 0, gated_total = 0, slow_total = 0;  // wave-uniform
+    uint32_t nitems = 0, gated_total = 0, slow_total = 0, general_strips = 0, fixed_strips = 0;  // wave-uniform
     const uint64_t nstrips = (a.n + kTileShift + kStrip - 1) / kStrip;
     // The raw IQ of a strip is fetched one strip ahead into registers (8 x 16 bytes per lane and raw vector), so
     // the HBM latency of strip k + 1 hides behind the gate / slicing stages of strip k.
@@ -697,9 +758,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
 #pragma unroll
             for (int r = 0; r < kRawVecs; ++r) pre[t][r] = src0[kRawVecs * 64 * t + r];
     };
+    uint32_t lut_min = 0x7fff7fffu;  // UC8: packed minimum of the strip's table reads
     auto direct_chunk = [&](int t) {
         if constexpr (FMT == kFmtUC8) {
-            return uc8_chunk(pre[t][0], sh.lut);
+            return pre[t][0];  // (not used: UC8 strips go through radial_issue / radial_take)
         } else if constexpr (FMT == kFmtMag16) {
             const uint4 x = pre[t][0];
             return make_uint4(x.x ^ kBias2, x.y ^ kBias2, x.z ^ kBias2, x.w ^ kBias2);
@@ -722,27 +784,81 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         wave_sync();
 
         // ---- convert.c: strip + halo -> magnitudes in LDS; comparisons of neighbours -> bit-sliced words
-        uint32_t accL[4] = {0, 0, 0, 0}, accG[4] = {0, 0, 0, 0};
+        uint32_t acc[4] = {0, 0, 0, 0};
         uint4 prev = make_uint4(0, 0, 0, 0);
         auto take_chunk = [&](int t, const uint4 o) {
             // the chunk after this lane's chunk of pass t - 1 is the next lane's, or (lane 63) lane 0's of this pass
-            if (t > 0) edge_accumulate(prev, from_next_lane(lane == 0 ? o.x : prev.x), accL, accG);
+            if (t > 0) edge_accumulate(prev, from_next_lane(lane == 0 ? o.x : prev.x), acc);
             prev = o;
         };
-        if (interior(strip)) {
+        bool general = !interior(strip);  // wave-uniform
+        if (!general) {
+            lut_min = 0x7fff7fffu;
+            if constexpr (FMT == kFmtUC8) {
+                const uint32_t lut_lds = (uint32_t)(uintptr_t)sh.lut;
+                RadialChunk rc[2];
+                radial_issue(pre[0][0], lut_lds, rc[0]);
 #pragma unroll
-            for (int t = 0; t < kPasses; ++t) {
-                const uint4 o = direct_chunk(t);
-                ((uint4 *)W.m)[(int)lane + 64 * t] = o;
-                take_chunk(t, o);
+                for (int t = 0; t < kPasses; ++t) {
+                    uint4 o;
+                    if (t + 1 < kPasses) {
+                        radial_issue(pre[t + 1][0], lut_lds, rc[(t + 1) & 1]);
+                        o = radial_take<8>(rc[t & 1], lut_min);
+                    } else {
+                        o = radial_take<0>(rc[t & 1], lut_min);
+                    }
+                    ((uint4 *)W.m)[(int)lane + 64 * t] = o;
+                    take_chunk(t, o);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < kPasses; ++t) {
+                    const uint4 o = direct_chunk(t);
+                    ((uint4 *)W.m)[(int)lane + 64 * t] = o;
+                    take_chunk(t, o);
+                }
             }
-        } else {
+            if constexpr (FMT == kFmtUC8) {
+                // a sample of the strip read an entry the radial table cannot hold (about one strip in fifteen on strong signals):
+                // those samples get their magnitude from the full table in global memory, the comparisons are taken again from LDS
+                const bool hit = (int16_t)lut_min == (int16_t)kRadialSentinel || (int16_t)(lut_min >> 16) == (int16_t)kRadialSentinel;
+                if (__ballot(hit) != 0) {  // wave-uniform
+                    wave_sync();
+                    if (hit) {
+#pragma unroll
+                        for (int t = 0; t < kPasses; ++t) {
+                            const uint4 raw = pre[t][0];
+                            uint4 o = ((const uint4 *)W.m)[(int)lane + 64 * t];
+                            const uint32_t X[4] = {raw.x, raw.y, raw.z, raw.w};
+                            uint32_t O[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                if ((O[k] & 0xffffu) == kRadialSentinel) O[k] = (O[k] & 0xffff0000u) | (a.tab.uc8_lut[X[k] & 0xffffu] ^ kBias);
+                                if ((O[k] >> 16) == kRadialSentinel) O[k] = (O[k] & 0xffffu) | ((a.tab.uc8_lut[X[k] >> 16] ^ kBias) << 16);
+                            }
+                            ((uint4 *)W.m)[(int)lane + 64 * t] = make_uint4(O[0], O[1], O[2], O[3]);
+                        }
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = 0;
+#pragma unroll
+                    for (int t = 0; t < kPasses; ++t) take_chunk(t, ((const uint4 *)W.m)[(int)lane + 64 * t]);
+                    fixed_strips += 1;
+                }
+            }
+        }
+        if (general) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = 0;
+            general_strips += 1;
+            wave_sync();
             fill_region_general<FMT>(a, W.m, s0, lane);
             wave_sync();
 #pragma unroll
             for (int t = 0; t < kPasses; ++t) take_chunk(t, ((const uint4 *)W.m)[(int)lane + 64 * t]);
         }
-        edge_accumulate(prev, from_next_lane(lane == 0 ? 0u : prev.x), accL, accG);  // chunk 511 has no successor: not a scan offset
+        edge_accumulate(prev, from_next_lane(lane == 0 ? 0u : prev.x), acc);  // chunk 511 has no successor: not a scan offset
         if (RSB_PREFETCH_EARLY && strip + 1 < strip_hi) prefetch(strip + 1);
         wave_sync();
         DBG_STAGE(0) DBG_COUNT(0, 1)
@@ -752,10 +868,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         uint32_t neq = 0;  // wave-uniform
         {
             uint32_t L[5], G[5];
-            L[0] = __builtin_amdgcn_perm(accL[1], accL[0], 0x07050301u);  // samples 0..3 of the lane's chunks
-            L[1] = __builtin_amdgcn_perm(accL[3], accL[2], 0x07050301u);  // samples 4..7
-            G[0] = __builtin_amdgcn_perm(accG[1], accG[0], 0x07050301u);
-            G[1] = __builtin_amdgcn_perm(accG[3], accG[2], 0x07050301u);
+            L[0] = __builtin_amdgcn_perm(acc[1], acc[0], 0x07050301u);  // samples 0..3 of the lane's chunks
+            L[1] = __builtin_amdgcn_perm(acc[3], acc[2], 0x07050301u);  // samples 4..7
+            G[0] = __builtin_amdgcn_perm(acc[1], acc[0], 0x06040200u);
+            G[1] = __builtin_amdgcn_perm(acc[3], acc[2], 0x06040200u);
             L[2] = next_chunk(L[0], lane);
             L[3] = next_chunk(L[1], lane);
             L[4] = next_chunk(L[2], lane);
@@ -898,7 +1014,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             const bool any_long = __ballot(lng) != 0;
             DBG_COUNT(3, 1) DBG_COUNT(6, (uint32_t)__popcll(__ballot(lng)))
             const uint32_t e0 = j + 19;
-            uint32_t c[15], D[8], N[6];
+            uint32_t c[15], D[8], NX[6], NY[6];
             load_coefs(sh.coef, e0, phase, c);
             uint32_t A = (uint32_t)(uintptr_t)W.m + ((e0 >> 1) << 2);  // LDS byte address of the window's first dword
             uint32_t T = (uint32_t)(uintptr_t)sh.gsyn + 4u * (lng ? kGsynLong : kGsynShort);  // ... of this group's syndrome row
@@ -906,17 +1022,20 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 lds_dword *mw = (lds_dword *)(uintptr_t)A;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) D[k] = mw[k];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) NY[k] = mw[8 + k];  // group 1's new dwords
             }
-            // Runtime loops (not 23 unrolled groups: the register allocator then keeps the whole stage in ~60 VGPRs).
-            // Per group: the next group's six new dwords go in flight first, the group's syndrome (crc.c:59-64,140:
-            // the CRC is linear) is looked up now and folded in one group later, so no group waits for LDS.
+            // Runtime loops (not 23 unrolled groups: the register allocator then keeps the whole stage in ~70 VGPRs).
+            // Per group: the six new dwords of the group AFTER THE NEXT go in flight first (one group of arithmetic did not
+            // cover the LDS latency with sixteen wavefronts on the bank: the wavefronts spent more of this stage waiting than
+            // issuing), the group's syndrome (crc.c:59-64,140: the CRC is linear) is looked up now and folded in one group later.
             uint32_t syn = 0, look = 0, hi = 0, lo = 0;  // hi:lo = the message bits so far (only the first 55 matter)
-            auto group = [&](bool more, uint32_t keep) {
+            auto group = [&](uint32_t (&load_into)[6], const uint32_t (&take_from)[6], bool more, uint32_t keep) {
                 asm volatile("" : "+v"(A), "+v"(T));  // one address register each, the rest in the instructions' offsets
                 lds_dword *mw = (lds_dword *)(uintptr_t)A;
                 if (more) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) N[k] = mw[8 + k];
+                    for (int k = 0; k < 6; ++k) load_into[k] = mw[14 + k];
                 }
                 const uint32_t b = slice_group(D, c) & keep;
                 syn ^= look;
@@ -924,29 +1043,37 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 D[0] = D[6];
                 D[1] = D[7];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) D[2 + k] = N[k];
+                for (int k = 0; k < 6; ++k) D[2 + k] = take_from[k];
                 A += 24;
                 T += 128;
                 return b;
             };
-            {  // bits 0..54: group 0, then five pairs (the window registers rotate with period two: no copies)
-                const uint32_t b = group(true, 31u);
-                lo = b;
-            }
-#pragma unroll 2
-            for (int u = 1; u < 11; ++u) {
-                const uint32_t b = group(true, 31u);
+            auto message_bits = [&](uint32_t b) {
                 hi = __builtin_amdgcn_alignbit(hi, lo, 27);
                 lo = (lo << 5) | b;
+            };
+            // even groups load into NX and take NY, odd groups the other way round; a frame's window of group g + 2 lies inside
+            // the region for every g + 2 <= 13 whatever the frame's length (13 * 12 + 19 + 12 < kHalo), beyond that only long frames go
+            lo = group(NX, NY, true, 31u);  // group 0
+            for (int u = 1; u < 9; u += 2) {
+                message_bits(group(NY, NX, true, 31u));
+                message_bits(group(NX, NY, true, 31u));
             }
+            message_bits(group(NY, NX, true, 31u));       // group 9 (loads 11's)
+            message_bits(group(NX, NY, any_long, 31u));   // group 10 (loads 12's)
             const uint32_t w0 = __builtin_amdgcn_alignbit(hi, lo, 23);  // message bits 0..31: DF + AA
             // group 11: a 56-bit frame ends with its first bit (bit 55)
-            const uint32_t b11 = group(any_long, lng ? 31u : 16u);
+            const uint32_t b11 = group(NY, NX, any_long, lng ? 31u : 16u);
             const uint32_t nz = hi | lo | b11;  // only 56-bit frames are checked for all-zero (mode_s.c:325)
             uint32_t syn_short = syn ^ look;
             if (any_long) {  // wave-uniform; lanes with 56-bit frames run along and are discarded below
-                for (int u = 12; u < 22; ++u) group(true, 31u);
-                group(false, 24u);  // group 22 holds bits 110..114: 110 and 111 belong to the frame
+                for (int u = 12; u < 20; u += 2) {
+                    group(NX, NY, true, 31u);
+                    group(NY, NX, true, 31u);
+                }
+                group(NX, NY, true, 31u);    // group 20 (loads 22's)
+                group(NY, NX, false, 31u);   // group 21
+                group(NX, NY, false, 24u);   // group 22 holds bits 110..114: 110 and 111 belong to the frame
                 syn ^= look;
             }
             syn = lng ? syn : syn_short;
@@ -966,6 +1093,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         a.region_counts[gwave] = nitems;
         if (gated_total) atomicAdd(&a.counters[kCntGated], gated_total);
         if (slow_total) atomicAdd(&a.counters[kCntSlowPath], slow_total);
+        if (general_strips) atomicAdd(&a.counters[kCntGeneralStrips], general_strips);
+        if (fixed_strips) atomicAdd(&a.counters[kCntFixedStrips], fixed_strips);
     }
 }
 

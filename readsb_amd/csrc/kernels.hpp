@@ -40,6 +40,8 @@ enum : int {
     kCntAccE0,         // device replay: accepted messages by corrected bits (0, 1, 2)
     kCntAccE1,
     kCntAccE2,
+    kCntGeneralStrips, // scan: strips converted sample by sample (first / last strips, unaligned input)
+    kCntFixedStrips,   // scan, UC8: strips with samples whose magnitude the radial table cannot hold (patched from the full table)
     kCntCount = 16,
     // RSB_STAGE_CLOCKS builds only: per-stage wave time of the scan kernel (s_memtime ticks >> 4) and work counts
     kDbgClkConvert = 16, kDbgClkEdge, kDbgClkGate, kDbgClkDf, kDbgClkSlice, kDbgStrips, kDbgGateBatches, kDbgDfBatches, kDbgSliceBatches,

@@ -462,3 +462,32 @@ def test_empty_batch_ends_the_recording(built):
     parts.append(ch.process_host(iq[131072:]))
     assert first_mismatch(want, np.concatenate(parts).view(REC_DTYPE)) is None
     ch.close()
+
+
+def test_uc8_table_exceptions_are_patched(built):
+    """k_scan looks UC8 magnitudes up by I (255 - I) + Q (255 - Q) (one v_dot4 per sample).  48 of the 65536 byte pairs -- two
+    values of that index -- have two different magnitudes in the reference's float table (convert.c:35-61): strips that meet
+    one are patched from the full table.  Full-scale random bytes meet them in every strip (and make the gate / slicer as
+    sensitive to single magnitudes as it gets); a low-amplitude recording never does and must stay on the table path."""
+    from readsb_amd.synth import Scenario
+
+    rng = np.random.default_rng(77)
+    quiet = generate(Scenario(1 << 21, seed=5, fmt="UC8", amp_lo=0.05, amp_hi=0.25))
+    loud = rng.integers(0, 256, size=(1 << 21, 2), dtype=np.uint8)
+    marked = generate(Scenario(1 << 21, seed=6, fmt="UC8"))
+    pairs = np.array([(16, 90), (39, 50), (239, 165), (216, 205), (31, 122), (38, 91), (224, 133), (217, 164), (47, 181), (103, 34)], dtype=np.uint8)
+    marked[5000::997] = pairs[np.arange(marked[5000::997].shape[0]) % len(pairs)]
+    for iq, patched in ((quiet, False), (np.concatenate([marked, loud, quiet]), True)):
+        want, wst = Oracle(fmt="UC8", nfix=1).run_stream(iq)
+        ch = readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=iq.shape[0], queue_div=8)
+        got = ch.process_host(iq, cap=want.size + 1024)
+        assert first_mismatch(want, got.view(REC_DTYPE)) is None
+        st = ch.stats()
+        assert st["demod_accepted"] == [wst["accepted0"], wst["accepted1"], wst["accepted2"]]
+        nstrips = (iq.shape[0] + 2767) // 2768
+        assert st["general_strips"] <= 8  # the first strip and the last ones of the recording
+        if patched:
+            assert st["patched_strips"] > nstrips // 3
+        else:
+            assert st["patched_strips"] == 0 and want.size > 100
+        ch.close()

@@ -26,11 +26,11 @@ void run(const char *name, int *out, int ncu) {
     const int iters = 20000;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int waves_per_simd : {1, 2, 3, 4}) {
-        const int threads = 256 * waves_per_simd;
-        hipLaunchKernelGGL((k<OP, ILP>), dim3(ncu), dim3(threads), 0, 0, out, 10, 1u);
+    for (int waves_per_simd : {1, 2, 4, 8}) {
+        const int threads = 256 * (waves_per_simd > 4 ? 4 : waves_per_simd); const int blocks_per_cu = waves_per_simd > 4 ? waves_per_simd / 4 : 1;
+        hipLaunchKernelGGL((k<OP, ILP>), dim3(ncu * blocks_per_cu), dim3(threads), 0, 0, out, 10, 1u);
         (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((k<OP, ILP>), dim3(ncu), dim3(threads), 0, 0, out, iters, 1u);
+        hipLaunchKernelGGL((k<OP, ILP>), dim3(ncu * blocks_per_cu), dim3(threads), 0, 0, out, iters, 1u);
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
