@@ -147,6 +147,9 @@ def main() -> int:
     ap.add_argument("--segment", type=int, default=1 << 23, help="synthetic segment that is tiled to --samples")
     ap.add_argument("--batches", type=int, default=1, help="submit the recording as this many batches")
     ap.add_argument("--in-flight", type=int, default=3, help="batches submitted ahead of the one being collected (the library holds up to 4)")
+    ap.add_argument("--steps-in-flight", type=int, default=2, choices=(1, 2),
+                    help="2: step k + 1 (its own receiver channel) is submitted before step k is collected, so the replay / copy tail of one "
+                         "recording runs beside the scan of the next; 1: strictly one step at a time")
     ap.add_argument("--scan-workgroups", type=int, default=-1, help="rsb_config.scan_workgroups: CUs the persistent scan kernel takes; -1 = all with one batch, "
                     "224 with several (one CU per shader engine stays free for the replay kernels of the batch before)")
     ap.add_argument("--output", choices=("records", "beast", "raw"), default="records",
@@ -203,11 +206,13 @@ def main() -> int:
     nb = max(1, args.batches)
     bs = -(-nc // nb) // 131072 * 131072 or nc
     cuts = list(range(0, nc, bs)) + [nc]
+    # two steps in flight: two receiver channels take the steps in turn (one channel, one batch per step, records out)
+    overlap = args.steps_in_flight == 2 and C == 1 and nb == 1 and args.output == "records" and not args.dcfilter
     scan_wgs = args.scan_workgroups if args.scan_workgroups >= 0 else (0 if nb == 1 else 224)
     chans = [readsb_amd.Channel(fmt=args.format, fix_bits=args.fix_bits, mode_ac=args.modeac, dc_filter=args.dcfilter, device=local_rank,
                                 max_batch_samples=max(b - a for a, b in zip(cuts, cuts[1:])), queue_div=16 if args.dense else 32,
                                 scan_workgroups=scan_wgs)
-             for _ in range(C)]
+             for _ in range(2 if overlap else C)]
     ch = chans[0]
     stream = torch.cuda.current_stream().cuda_stream
     cap = max(1 << 16, n // (256 if args.dense else 512))
@@ -268,16 +273,57 @@ def main() -> int:
     def barrier():
         rd.barrier(dev)
 
+    outbuf2 = torch.empty(cap * readsb_amd.MSG_DTYPE.itemsize if overlap else 1, dtype=torch.uint8, pin_memory=True).numpy().view(
+        readsb_amd.MSG_DTYPE if overlap else np.uint8)
+
+    def steps_overlapped(count, tm=None):
+        """count steps, every one the whole recording from a cold filter on the receiver channel whose turn it is (two channels, two
+        pinned result buffers).  A step's records cross PCIe (rsb_collect_begin .. rsb_collect_wait) while the next step's scan
+        runs; everything else of a step -- scan, prune, replay, emit -- runs one after the other as before.  Returns the last
+        step's records (complete: the last wait is inside)."""
+        bufs = (outbuf, outbuf2)
+        out = None
+        chans[0].reset()
+        chans[0].submit(base, nc, stream)
+        for k in range(count):
+            c, o = chans[k % 2], chans[(k + 1) % 2]
+            if k > 0:
+                o.collect_wait()               # step k - 1's records are in host memory (their copy ran beside step k's scan)
+            if k + 1 < count:
+                o.reset()                      # the other channel's next recording starts cold; done while step k's scan runs
+            out = c.collect_begin(bufs[k % 2])  # waits for step k's scan, prune, replay and emit; its copy is under way
+            if k + 1 < count:
+                o.submit(base, nc, stream)
+            if tm is not None:
+                t = c.timing()
+                for key in keys:
+                    tm[key].append(t[key])
+        chans[(count - 1) % 2].collect_wait()
+        chan_msgs[1] = out.size
+        return out
+
     for _ in range(args.warmup):
         msgs = step()
+        if overlap:
+            msgs = steps_overlapped(2)
     tm = {k: [] for k in keys}
     scan_ms = tm["scan_ms"]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        msgs = step(tm)
+    if overlap:
+        msgs = steps_overlapped(args.steps, tm)
+    else:
+        for _ in range(args.steps):
+            msgs = step(tm)
     barrier()
     dt = time.perf_counter() - t0
+    serial_ms = None
+    if overlap:  # for the record, outside the timed region: the same steps one at a time (submit -> collect latency of one recording)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+        serial_ms = (time.perf_counter() - t1) / 2 * 1e3
     dt = rd.max_over_ranks(dt, dev)                      # the slowest rank's time
     wire_check = None
     if args.output != "records":
@@ -352,6 +398,8 @@ def main() -> int:
                        "samples_per_gpu": n, "segment_samples": seg_n, "format": args.format, "fix_bits": args.fix_bits,
                        "mode_ac": bool(args.modeac), "dc_filter": bool(args.dcfilter),
                        "batches_per_step": len(cuts) - 1, "batches_in_flight": min(args.in_flight, len(cuts) - 1), "scan_workgroups": scan_wgs or "all",
+                       "steps_in_flight": 2 if overlap else 1,
+                       **({"ms_per_step_one_at_a_time": serial_ms} if serial_ms is not None else {}),
                        "channels": world * C, "channels_per_gpu": C, "messages_per_step": nmsgs, "survivors_per_step": st["survivors"],
                        "full_size_check": parity, "oracle_check": oracle_check, "ranks_with_checks_ok": checks_ok, "output": args.output,
                        **({"wire_bytes_per_step": int(wire_bytes.size), "wire_check": wire_check} if wire_check else {})},

@@ -193,6 +193,16 @@ int rsb_submit(rsb_ctx *ctx, const void *iq_dev, uint64_t nsamples, void *stream
  * cap only the first cap are stored and RSB_EOVERFLOW is returned). */
 int rsb_collect(rsb_ctx *ctx, rsb_message *out, size_t cap, size_t *n_out);
 
+/* rsb_collect in two halves, for callers that keep the GPU busy while a batch's records cross PCIe (41 MB per Gsample of the
+ * benchmark's traffic: 0.73 ms at link speed).  rsb_collect_begin returns once the batch's messages are final on the device and
+ * their copy into out[] (pinned host memory, or the call simply blocks) is under way on the library's copy stream: *n_out is
+ * valid, out[] is not yet.  The caller may rsb_submit the next batch -- its scan then runs beside the copy -- and calls
+ * rsb_collect_wait before reading out[].  Any later rsb_collect* / rsb_reset / rsb_destroy on the context waits by itself.
+ * Paths that finish on the host (RSB_FLAG_HOST_REPLAY, Mode A/C lists merged on the host) deliver in _begin; _wait is then a no-op.
+ * No counterpart in the reference (readsb.c:883-886 hands messages over one by one). */
+int rsb_collect_begin(rsb_ctx *ctx, rsb_message *out, size_t cap, size_t *n_out);
+int rsb_collect_wait(rsb_ctx *ctx);
+
 /* rsb_submit + rsb_collect */
 int rsb_process(rsb_ctx *ctx, const void *iq_dev, uint64_t nsamples, void *stream,
                 rsb_message *out, size_t cap, size_t *n_out);

@@ -73,6 +73,8 @@ SYMBOLS = {
     "rsb_superset_add": (C.c_int, [_VP, _VP, _SZ]),
     "rsb_filter_export": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_collect": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
+    "rsb_collect_begin": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
+    "rsb_collect_wait": (C.c_int, [_VP]),
     "rsb_process": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_process_host": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_get_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
@@ -239,6 +241,18 @@ class Channel:
             raise RsbError(f"rsb_collect: {n.value} messages exceed cap {cap}")
         self._check(rc, "rsb_collect")
         return out[:n.value]
+
+    def collect_begin(self, out: np.ndarray) -> np.ndarray:
+        """rsb_collect_begin: the returned slice of `out` (pinned memory) holds the records only after collect_wait()."""
+        n = _SZ()
+        rc = self.l.rsb_collect_begin(self.h, out.ctypes.data, out.size, C.byref(n))
+        if rc == -4 and n.value > out.size:
+            raise RsbError(f"rsb_collect_begin: {n.value} messages exceed cap {out.size}")
+        self._check(rc, "rsb_collect_begin")
+        return out[:n.value]
+
+    def collect_wait(self):
+        self._check(self.l.rsb_collect_wait(self.h), "rsb_collect_wait")
 
     def collect_wire(self, wire: str = "beast", mlat: bool = True, cap_bytes: int = 1 << 20, out: np.ndarray | None = None):
         """rsb_collect_wire: the submitted batch as Beast / raw bytes -> (bytes, number of messages in the batch)"""

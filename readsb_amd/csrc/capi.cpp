@@ -439,6 +439,7 @@ int rsb_create(const rsb_config *cfg, rsb_ctx **out) {
 void rsb_destroy(rsb_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
+    if (c->copy_in_flight && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
                     c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
                     c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge};
@@ -463,6 +464,7 @@ void rsb_destroy(rsb_ctx *c) {
 
 int rsb_reset(rsb_ctx *c) {
     if (!c) return RSB_EINVAL;
+    (void)rsb_collect_wait(c);
     if (c->any_pending()) {  // a batch still in flight: wait for its kernels, then forget it
         (void)hipSetDevice(c->cfg.device);
         (void)hipDeviceSynchronize();
@@ -946,7 +948,10 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
             if (list != b.d_out) HIP_TRY(c, hipStreamSynchronize(s));  // (a merged list: its kernel ran on the replay stream)
             if (ncopy) HIP_TRY(c, hipMemcpyAsync(out, list, ncopy * sizeof(rsb_message), hipMemcpyDeviceToHost, c->copy_stream));
             collect_ahead(c);
-            HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+            if (c->defer_copy_wait && ncopy)
+                c->copy_in_flight = true;  // rsb_collect_begin: the caller comes back with rsb_collect_wait
+            else
+                HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
             delivered = true;
         } else {
             c->dev_msgs.resize(nacc);
@@ -1041,14 +1046,38 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
 
 extern "C" {
 
+int rsb_collect_wait(rsb_ctx *c) {
+    if (!c) return RSB_EINVAL;
+    if (c->copy_in_flight) {
+        c->copy_in_flight = false;
+        HIP_TRY(c, hipSetDevice(c->cfg.device));
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    }
+    return RSB_OK;
+}
+
 int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     if (!c || (!out && cap)) return RSB_EINVAL;
+    int rc = rsb_collect_wait(c);  // a copy left in flight by rsb_collect_begin
+    if (rc != RSB_OK) return rc;
     return collect_impl(c, out, cap, n_out, nullptr);
+}
+
+int rsb_collect_begin(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
+    if (!c || (!out && cap)) return RSB_EINVAL;
+    int rc = rsb_collect_wait(c);
+    if (rc != RSB_OK) return rc;
+    c->defer_copy_wait = true;
+    rc = collect_impl(c, out, cap, n_out, nullptr);
+    c->defer_copy_wait = false;
+    if (rc != RSB_OK && rc != RSB_EOVERFLOW) (void)rsb_collect_wait(c);
+    return rc;
 }
 
 int rsb_collect_wire(rsb_ctx *c, int wire, uint32_t flags, uint8_t *out, size_t cap, size_t *nbytes, size_t *n_msgs) {
     if (!c || (!out && cap) || !nbytes || (wire != RSB_WIRE_BEAST && wire != RSB_WIRE_RAW)) return RSB_EINVAL;
     *nbytes = 0;
+    if (rsb_collect_wait(c) != RSB_OK) return RSB_ENODEV;
     WireRequest w{wire, flags, out, cap, 0};
     const int rc = collect_impl(c, nullptr, 0, n_msgs, &w);
     *nbytes = w.nbytes;

@@ -491,3 +491,44 @@ def test_uc8_table_exceptions_are_patched(built):
         else:
             assert st["patched_strips"] == 0 and want.size > 100
         ch.close()
+
+
+def test_collect_in_two_halves(built):
+    """rsb_collect_begin / rsb_collect_wait: the records of batch k cross PCIe while batch k + 1 is scanned (what bench.py does
+    with its two channels).  Same lists as rsb_collect, batch by batch; a second begin, a plain collect and a reset wait by themselves."""
+    import torch
+
+    sc, kw = SCENARIOS["mixed_fix1"]
+    iq = generate(sc)
+    nb = 4 * 131072
+    cuts = list(range(0, iq.shape[0], nb)) + [iq.shape[0]]
+    dev = torch.from_numpy(iq).cuda()
+    ref = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], max_batch_samples=nb)
+    want = []
+    for a, b in zip(cuts, cuts[1:]):
+        ref.submit(dev.data_ptr() + 2 * a, b - a)
+        want.append(ref.collect(cap=1 << 15).copy())
+    ref.close()
+    assert sum(w.size for w in want) > 1000
+    bufs = [torch.empty((1 << 15) * 56, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE) for _ in range(2)]
+    for explicit_wait in (True, False):
+        ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], max_batch_samples=nb)
+        got = [None] * len(want)
+        ch.submit(dev.data_ptr(), cuts[1])
+        for k in range(len(want)):
+            out = ch.collect_begin(bufs[k % 2])
+            assert out.size == want[k].size  # the count is final at once
+            if k + 1 < len(want):
+                ch.submit(dev.data_ptr() + 2 * cuts[k + 1], cuts[k + 2] - cuts[k + 1])  # scanned beside the copy
+            if explicit_wait:
+                ch.collect_wait()
+                got[k] = out.copy()
+            elif k > 0:
+                got[k - 1] = prev.copy()  # the begin above waited for the copy before it
+            prev = out
+        if not explicit_wait:
+            ch.reset()  # waits as well
+            got[-1] = prev.copy()
+        for k in range(len(want)):
+            assert first_mismatch(want[k].view(REC_DTYPE), got[k].view(REC_DTYPE)) is None
+        ch.close()
