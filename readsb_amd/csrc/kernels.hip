@@ -42,6 +42,15 @@
 #define DBG_COUNT(k, n)
 #define DBG_FLUSH
 #endif
+#ifndef RSB_RADIAL_DEPTH
+#define RSB_RADIAL_DEPTH 2
+#endif
+#ifndef RSB_SLICE_AHEAD
+#define RSB_SLICE_AHEAD 2
+#endif
+#ifndef RSB_LATE_PASSES
+#define RSB_LATE_PASSES 0
+#endif
 #ifndef RSB_PREFETCH_EARLY
 #define RSB_PREFETCH_EARLY 1
 #endif
@@ -749,15 +758,21 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         const int64_t q = (int64_t)(strip * kStrip) - kTileShift - (int64_t)kTrailing;
         return kVecFmt && a.iq_aligned && strip < nstrips && q >= 0 && q + kRegion <= (int64_t)a.n;
     };
-    auto prefetch = [&](uint64_t strip) {
+    // The last kLatePasses chunks of a strip are fetched at the top of the strip itself (they are converted last, behind the table
+    // reads of the others): 4 registers per raw vector and pass that the slicing stage of the strip before does not have to carry.
+    constexpr int kLatePasses = RSB_LATE_PASSES;
+    auto fetch_passes = [&](uint64_t strip, int t_lo, int t_hi) {
         if (!interior(strip)) return;
         const int64_t q = (int64_t)(strip * kStrip) - kTileShift - (int64_t)kTrailing;
         const uint4 *src0 = (const uint4 *)((const uint8_t *)a.iq + kBps * q) + kRawVecs * (int)lane;
 #pragma unroll
         for (int t = 0; t < kPasses; ++t)
+            if (t >= t_lo && t < t_hi) {
 #pragma unroll
-            for (int r = 0; r < kRawVecs; ++r) pre[t][r] = src0[kRawVecs * 64 * t + r];
+                for (int r = 0; r < kRawVecs; ++r) pre[t][r] = src0[kRawVecs * 64 * t + r];
+            }
     };
+    auto prefetch = [&](uint64_t strip) { fetch_passes(strip, 0, kPasses - kLatePasses); };
     uint32_t lut_min = 0x7fff7fffu;  // UC8: packed minimum of the strip's table reads
     auto direct_chunk = [&](int t) {
         if constexpr (FMT == kFmtUC8) {
@@ -781,6 +796,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     for (uint64_t strip = strip_lo; strip < strip_hi; strip += strip_step) {
         const int64_t s0 = (int64_t)(strip * kStrip) - kTileShift;  // S index of m[0]
         if (!RSB_PREFETCH_EARLY) prefetch(strip);
+        if (kLatePasses) fetch_passes(strip, kPasses - kLatePasses, kPasses);
         wave_sync();
 
         // ---- convert.c: strip + halo -> magnitudes in LDS; comparisons of neighbours -> bit-sliced words
@@ -797,11 +813,14 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             if constexpr (FMT == kFmtUC8) {
                 const uint32_t lut_lds = (uint32_t)(uintptr_t)sh.lut;
                 RadialChunk rc[2];
-                radial_issue(pre[0][0], lut_lds, rc[0]);
+                if (RSB_RADIAL_DEPTH == 2) radial_issue(pre[0][0], lut_lds, rc[0]);
 #pragma unroll
                 for (int t = 0; t < kPasses; ++t) {
                     uint4 o;
-                    if (t + 1 < kPasses) {
+                    if (RSB_RADIAL_DEPTH == 1) {  // the table reads of a chunk are waited for at once (16 registers less in this stage)
+                        radial_issue(pre[t][0], lut_lds, rc[0]);
+                        o = radial_take<0>(rc[0], lut_min);
+                    } else if (t + 1 < kPasses) {
                         radial_issue(pre[t + 1][0], lut_lds, rc[(t + 1) & 1]);
                         o = radial_take<8>(rc[t & 1], lut_min);
                     } else {
@@ -859,10 +878,13 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             for (int t = 0; t < kPasses; ++t) take_chunk(t, ((const uint4 *)W.m)[(int)lane + 64 * t]);
         }
         edge_accumulate(prev, from_next_lane(lane == 0 ? 0u : prev.x), acc);  // chunk 511 has no successor: not a scan offset
-        if (RSB_PREFETCH_EARLY && strip + 1 < strip_hi) prefetch(strip + 1);
+        if (RSB_PREFETCH_EARLY == 1 && strip + 1 < strip_hi) prefetch(strip + 1);
         wave_sync();
         DBG_STAGE(0) DBG_COUNT(0, 1)
-        if (a.stage_limit < 2) continue;
+        if (a.stage_limit < 2) {
+            if (RSB_PREFETCH_EARLY == 2 && strip + 1 < strip_hi) prefetch(strip + 1);
+            continue;
+        }
 
         // ---- demod_2400.c:109-155, edge patterns only, bit-parallel: 4 offsets x 8 passes per lane and instruction
         uint32_t neq = 0;  // wave-uniform
@@ -905,7 +927,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         }
         wave_sync();
         DBG_STAGE(1) DBG_COUNT(4, neq)
-        if (a.stage_limit < 3) continue;
+        if (a.stage_limit < 3) {
+            if (RSB_PREFETCH_EARLY == 2 && strip + 1 < strip_hi) prefetch(strip + 1);
+            continue;
+        }
 
         // ---- the whole gate (:109-172) on the edge candidates; survivors go to the gated queue
         uint32_t ngated = 0;  // wave-uniform
@@ -940,7 +965,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         gated_total += ngated;
         DBG_STAGE(2) DBG_COUNT(1, (neq + 63) / 64)
         if (ngated > (uint32_t)kGateCap) slow_total += ngated - kGateCap;
-        if (a.stage_limit < 4) continue;
+        if (a.stage_limit < 4) {
+            if (RSB_PREFETCH_EARLY == 2 && strip + 1 < strip_hi) prefetch(strip + 1);
+            continue;
+        }
         const uint32_t ngq = min(ngated, (uint32_t)kGateCap);
         // The gated offsets in ascending order (the edge queue is filled bit by bit, not offset by offset): rank by counting, the
         // queue is short (about 25 entries).  From here on everything keeps that order -- (offset, phase) pairs, the frame list,
@@ -996,8 +1024,12 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         if (nlist > (uint32_t)kListCap) slow_total += nlist - kListCap;
         wave_sync();
         DBG_STAGE(3) DBG_COUNT(2, (5 * ngq + 63) / 64)
-        if (a.stage_limit < 5) continue;
+        if (a.stage_limit < 5) {
+            if (RSB_PREFETCH_EARLY == 2 && strip + 1 < strip_hi) prefetch(strip + 1);
+            continue;
+        }
 
+        if (RSB_PREFETCH_EARLY == 2 && strip + 1 < strip_hi) prefetch(strip + 1);  // the slicing stage (~45 % of a strip's time) covers the HBM latency
         // ---- one lane per frame: 12 (56 bits) or 23 (112 bits) groups of five bits
         const uint32_t nfl = min(nlist, (uint32_t)kListCap);
         for (uint32_t cb = 0; cb < nfl; cb += 64) {
@@ -1018,24 +1050,28 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             load_coefs(sh.coef, e0, phase, c);
             uint32_t A = (uint32_t)(uintptr_t)W.m + ((e0 >> 1) << 2);  // LDS byte address of the window's first dword
             uint32_t T = (uint32_t)(uintptr_t)sh.gsyn + 4u * (lng ? kGsynLong : kGsynShort);  // ... of this group's syndrome row
+            constexpr int kAhead = RSB_SLICE_AHEAD;  // how many groups ahead of its use a window's six new dwords are requested
+            static_assert(kAhead == 1 || kAhead == 2, "");
             {
                 lds_dword *mw = (lds_dword *)(uintptr_t)A;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) D[k] = mw[k];
+                if (kAhead == 2) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) NY[k] = mw[8 + k];  // group 1's new dwords
+                    for (int k = 0; k < 6; ++k) NY[k] = mw[8 + k];  // group 1's new dwords
+                }
             }
             // Runtime loops (not 23 unrolled groups: the register allocator then keeps the whole stage in ~70 VGPRs).
-            // Per group: the six new dwords of the group AFTER THE NEXT go in flight first (one group of arithmetic did not
-            // cover the LDS latency with sixteen wavefronts on the bank: the wavefronts spent more of this stage waiting than
-            // issuing), the group's syndrome (crc.c:59-64,140: the CRC is linear) is looked up now and folded in one group later.
+            // Per group: the six new dwords of a later group go in flight first (kAhead groups later: with 2 the wavefronts wait
+            // less in this stage, but the kernel then needs 128 VGPRs and spills a prefetch register to scratch: RSB_SLICE_AHEAD),
+            // the group's syndrome (crc.c:59-64,140: the CRC is linear) is looked up now and folded in one group later.
             uint32_t syn = 0, look = 0, hi = 0, lo = 0;  // hi:lo = the message bits so far (only the first 55 matter)
-            auto group = [&](uint32_t (&load_into)[6], const uint32_t (&take_from)[6], bool more, uint32_t keep) {
+            auto group_io = [&](uint32_t (&load_into)[6], const uint32_t (&take_from)[6], bool more, uint32_t keep) {
                 asm volatile("" : "+v"(A), "+v"(T));  // one address register each, the rest in the instructions' offsets
                 lds_dword *mw = (lds_dword *)(uintptr_t)A;
                 if (more) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) load_into[k] = mw[14 + k];
+                    for (int k = 0; k < 6; ++k) load_into[k] = mw[2 + 6 * kAhead + k];
                 }
                 const uint32_t b = slice_group(D, c) & keep;
                 syn ^= look;
@@ -1048,32 +1084,38 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 T += 128;
                 return b;
             };
+            // group g: with kAhead == 2 even groups load into NX and take NY, odd groups the other way round; with 1 everything
+            // goes through NY.  Group g + kAhead is fetched if the frame (or, past group 11, any frame of the batch) has it: the
+            // windows up to group 13 lie inside the region whatever the frame's length (13 * 12 + 19 + 12 < kHalo).
+            auto group = [&](int g, uint32_t keep) {
+                const bool more = g + kAhead <= 11 || (any_long && g + kAhead <= 22);
+                if (kAhead == 1) return group_io(NY, NY, more, keep);
+                return (g & 1) ? group_io(NY, NX, more, keep) : group_io(NX, NY, more, keep);
+            };
             auto message_bits = [&](uint32_t b) {
                 hi = __builtin_amdgcn_alignbit(hi, lo, 27);
                 lo = (lo << 5) | b;
             };
-            // even groups load into NX and take NY, odd groups the other way round; a frame's window of group g + 2 lies inside
-            // the region for every g + 2 <= 13 whatever the frame's length (13 * 12 + 19 + 12 < kHalo), beyond that only long frames go
-            lo = group(NX, NY, true, 31u);  // group 0
-            for (int u = 1; u < 9; u += 2) {
-                message_bits(group(NY, NX, true, 31u));
-                message_bits(group(NX, NY, true, 31u));
+            lo = group(0, 31u);
+            for (int u = 1; u < 9; u += 2) {  // (g + kAhead <= 11 for all of these: the flag folds)
+                message_bits(group(1, 31u));
+                message_bits(group(2, 31u));
             }
-            message_bits(group(NY, NX, true, 31u));       // group 9 (loads 11's)
-            message_bits(group(NX, NY, any_long, 31u));   // group 10 (loads 12's)
+            message_bits(group(9, 31u));
+            message_bits(group(10, 31u));
             const uint32_t w0 = __builtin_amdgcn_alignbit(hi, lo, 23);  // message bits 0..31: DF + AA
             // group 11: a 56-bit frame ends with its first bit (bit 55)
-            const uint32_t b11 = group(NY, NX, any_long, lng ? 31u : 16u);
+            const uint32_t b11 = group(11, lng ? 31u : 16u);
             const uint32_t nz = hi | lo | b11;  // only 56-bit frames are checked for all-zero (mode_s.c:325)
             uint32_t syn_short = syn ^ look;
             if (any_long) {  // wave-uniform; lanes with 56-bit frames run along and are discarded below
                 for (int u = 12; u < 20; u += 2) {
-                    group(NX, NY, true, 31u);
-                    group(NY, NX, true, 31u);
+                    group(12, 31u);
+                    group(13, 31u);
                 }
-                group(NX, NY, true, 31u);    // group 20 (loads 22's)
-                group(NY, NX, false, 31u);   // group 21
-                group(NX, NY, false, 24u);   // group 22 holds bits 110..114: 110 and 111 belong to the frame
+                group(20, 31u);
+                group(21, 31u);
+                group(22, 24u);  // group 22 holds bits 110..114: 110 and 111 belong to the frame
                 syn ^= look;
             }
             syn = lng ? syn : syn_short;

@@ -38,7 +38,7 @@ sha = hashlib.sha256()
 for f in ("kernels.hip", "kernels.hpp"):
     sha.update(open(os.path.join(root, "readsb_amd", "csrc", f), "rb").read())
 head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-out = {"kernel": "k_scan<UC8>", "command": "python3 bench.py --warmup 1 --no-cpu-baseline --steps 2 (one rocprofv3 --pmc pass per counter group)",
+out = {"kernel": "k_scan<UC8>", "command": "python3 bench.py --warmup 1 --no-cpu-baseline --steps-in-flight 1 --steps 2 (one rocprofv3 --pmc pass per counter group; kernel trace: the default command)",
        "git_head_at_summary": head, "kernel_src_sha256": sha.hexdigest(), "samples_per_launch": samples,
        "launches_averaged": {k: len(v) for k, v in cnt.items()}, "per_launch": per}
 d = {}
@@ -56,7 +56,10 @@ if "SQ_ACTIVE_INST_VALU" in per and "SQ_BUSY_CYCLES" in per:
         cyc = per["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
         d["launch_cycles_grbm"] = cyc
         d["effective_clock_GHz"] = cyc / scan_avg_ns
-        d["valu_utilisation"] = per["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)
+        # issue cost measured with tools/ubench_ops.hip (profiles/r2_valu_issue_cost.txt): 64-bit encodings (VOP3, VOP3P, SDWA, DPP) 4 cycles
+        # per wave-instruction and SIMD, 32-bit encodings (VOP1/VOP2) ~2.4: the busy share of the VALU lies between the two
+        d["valu_busy_if_every_instruction_costs_4_cycles"] = per["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc)
+        d["valu_busy_if_every_instruction_costs_2.4_cycles"] = per["SQ_INSTS_VALU"] * 2.4 / (1024.0 * cyc)
         d["lds_busy_fraction"] = per.get("SQ_LDS_IDX_ACTIVE", 0) / (256.0 * cyc)
     if per.get("SQ_LDS_IDX_ACTIVE"):
         d["lds_bank_conflict_share_of_lds_cycles"] = per.get("SQ_LDS_BANK_CONFLICT", 0) / per["SQ_LDS_IDX_ACTIVE"]
@@ -73,6 +76,10 @@ if "TCC_EA0_RDREQ_sum" in per:
     d["ea_bytes_if_other_requests_are_128B"] = (rall - r32) * 128 + r32 * 32
     if per.get("TCC_HIT_sum") is not None:
         d["l2_hit_rate"] = per["TCC_HIT_sum"] / max(1.0, per["TCC_HIT_sum"] + per.get("TCC_MISS_sum", 0))
+if all(k in per for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")):
+    wc = per["SQ_WAVE_CYCLES"]
+    d["wave_time_share"] = {"issuing": per["SQ_ACTIVE_INST_ANY"] / wc, "ready_but_not_issued": per["SQ_WAIT_INST_ANY"] / wc,
+                            "waiting_on_s_waitcnt": per["SQ_WAIT_ANY"] / wc}
 out["derived"] = d
 with open(os.path.join(dst, f"{tag}_pmc_scan.json"), "w") as f:
     json.dump(out, f, indent=1)
