@@ -150,3 +150,18 @@ def test_full_stats_fixture_agrees_with_message_fixtures():
         peak = float.fromhex(ref["peak_signal_power"])
         assert peak == (float(modes["signal"].max()) if modes.size else 0.0)  # :359-360
         assert math.isnan(float.fromhex(ref["noise_power_sum"])) == (SCENARIOS[name][0].n_samples % 131072 == 0)
+
+
+def test_reference_cli_prints_the_golden_lists(built):
+    """the golden lists come from oracle/_ref/ref_harness (the reference's objects behind a capture of
+    useModesMessage); this pins that harness to the reference's own program: `readsb --device-type ifile --raw --mlat` prints
+    the same (timestamp, frame) lines.  oracle/pin_cli.py; all six UC8 scenarios recorded in profiles/r2_cli_pin.txt."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "readsb")):
+        pytest.skip("oracle/_ref/readsb not built (make -C oracle ref, build container only)")
+    out = subprocess.run([sys.executable, os.path.join(root, "oracle", "pin_cli.py"), "cfg1_df11_df17", "nofix"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("IDENTICAL") == 2
