@@ -31,6 +31,11 @@ SCENARIOS.update({
     "uc8_dc": (Scenario(600_000, seed=6, dc_offset=0.03), dict(nfix=1, modeac=False, dc_filter=True)),
     "sc16_dc": (Scenario(600_000, seed=5, fmt="SC16", dc_offset=0.02), dict(nfix=1, modeac=False, dc_filter=True)),
     "sc16q11_dc_ac": (Scenario(600_000, seed=5, fmt="SC16Q11", dc_offset=0.02, modeac_per_sec=300), dict(nfix=1, modeac=True, dc_filter=True)),
+    # --dcfilter at high SNR (SURVEY B.7 ii): strong clean frames only, so no frame sits at the slicer's decision margin and the
+    # device's message SET must be the reference's (fields that depend on magnitudes keep the test's tolerance)
+    "sc16_dc_highsnr": (Scenario(900_000, seed=9, fmt="SC16", dc_offset=0.02, amp_lo=0.3, amp_hi=0.8, noise_lsb=1.0, err1_every=0,
+                                 collide_every=0, df11_iid_every=0, mix={"df17": 0.7, "df11": 0.3}),
+                        dict(nfix=1, modeac=False, dc_filter=True, same_set=True)),
     "sc16_ac": (Scenario(600_000, seed=13, fmt="SC16", modeac_per_sec=300), dict(nfix=1, modeac=True)),
 })
 

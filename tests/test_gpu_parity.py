@@ -38,11 +38,14 @@ def test_dcfilter_stream(name, built):
     """--dcfilter (BASELINE config 3).  The reference's DC block (convert.c:137-140) is a float32 recurrence run sample by
     sample; its rounding noise alone moves it several magnitude LSBs away from the exact recurrence within a few 10^5
     samples, and no reassociated (parallel) evaluation can follow that noise.  The device evaluates the recurrence as a
-    chunked scan in double.  TOLERANCE ORACLE, in three parts:
-      1. converter: every magnitude within +-1 LSB of the exact (double) recurrence, and within +-24 LSB of the reference's;
+    chunked scan in double.  TOLERANCE ORACLE, in three parts, the bounds pinned by measurement (tools/dc_tolerance.py on the
+    MI355X -> profiles/r2_dcfilter_tolerance.json; each bound is twice what was observed):
+      1. converter: every magnitude within +-1 LSB of the exact (double) recurrence; within +-18 LSB (UC8: 9 observed, which
+         is also how far the reference itself is from the exact recurrence) / +-4 LSB (SC16, SC16Q11: 2 observed) of the reference's;
       2. demodulators: on the device's magnitudes the message list is BIT-EXACT against the oracle run on those magnitudes;
-      3. end to end against the reference: messages present in both lists agree in every field (signal level to 1 %),
-         and at most 2 % of the messages are in only one of the lists (frames at the slicer's decision margin)."""
+      3. end to end against the reference: messages present in both lists agree in every field (signal level to 0.5 % UC8,
+         0.1 % SC16: 0.22 % / 0.03 % observed); UC8: at most 2 messages in only one list (1 of 377 observed: a frame at the
+         slicer's decision margin); SC16 / SC16Q11 and the high-SNR fixture (SURVEY B.7 ii): the SAME message set."""
     from scipy.signal import lfilter
 
     sc, kw = SCENARIOS[name]
@@ -68,7 +71,8 @@ def test_dcfilter_stream(name, built):
     exact = np.floor(np.sqrt(np.minimum(1.0, (y * y).sum(axis=1))) * 65535.0 + 0.5).astype(np.int64)
     refmag = np.concatenate([Oracle(fmt=sc.fmt, dc_filter=True).convert(iq)[0]]).astype(np.int64)
     assert np.abs(mag.astype(np.int64) - exact).max() <= 1
-    assert np.abs(mag.astype(np.int64) - refmag).max() <= 24
+    lsb, one_sided, rel = {"UC8": (18, 2, 0.005)}.get(sc.fmt, (4, 0, 0.001))
+    assert np.abs(mag.astype(np.int64) - refmag).max() <= lsb
 
     # 2. demodulators, bit-exact on the same magnitudes
     on_mags = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_mag_stream(mag, means)
@@ -78,12 +82,12 @@ def test_dcfilter_stream(name, built):
     key = lambda r: (int(r["ts"]), bytes(r["msg"]), int(r["msgbits"]))
     rd, gd = {key(r): r for r in ref}, {key(r): r for r in got}
     common = rd.keys() & gd.keys()
-    assert len(rd.keys() ^ gd.keys()) <= 0.02 * max(len(rd), 1)
+    assert len(rd.keys() ^ gd.keys()) <= (0 if kw.get("same_set") else one_sided)
     for k in common:
         a, b = rd[k], gd[k]
         for f in ("msgtype", "crc", "correctedbits", "addr", "score", "source", "iid"):
             assert a[f] == b[f], (k, f)
-        assert abs(a["signal"] - b["signal"]) <= 0.01 * abs(a["signal"]) + 1e-12
+        assert abs(a["signal"] - b["signal"]) <= rel * abs(a["signal"]) + 1e-12
 
 
 @REPLAY
