@@ -240,6 +240,20 @@ typedef struct rsb_stream rsb_stream;
 typedef void (*rsb_stream_sink)(void *user, const rsb_message *msgs, size_t n);
 int rsb_stream_open(rsb_ctx *ctx, uint32_t blocks_per_batch, rsb_stream_sink sink, void *user, rsb_stream **out);
 int rsb_stream_push(rsb_stream *st, const void *iq_host, uint32_t nsamples, uint64_t dropped_before);
+/* The bladeRF's framing (sdr_bladerf.c:335-394): one transfer buffer as its stream callback receives it, `bytes` long, made of
+ * sub-blocks of block_size bytes = a 16-byte metadata header (magic 0x12344321, 64-bit hardware timestamp at +4, status flags at
+ * +12, little endian) followed by (block_size - 16) / 4 SC16Q11 samples.  Headers are stripped and the samples staged back to
+ * back; a wrong magic ends the buffer (the reference skips its rest, :347-353); *overruns receives the number of sub-blocks
+ * flagged BLADERF_META_STATUS_OVERRUN.  A timestamp that is not the expected one means lost samples (:366-375): as the reference,
+ * the part of THIS buffer before that sub-block is discarded, what was staged earlier is decoded, and the stream restarts at the
+ * new position from a zero carry -- message timestamps keep following the hardware timestamp (timestamp / decimation samples
+ * from the first buffer's).  rsb_stream_flush on such a stream submits whole 131072-sample blocks only.
+ * PARITY UNPINNED: the handler needs libbladeRF and cannot run in the build container; what is tested is that the de-framed
+ * stream decodes exactly as the same samples pushed plainly.  Known difference: the reference's mag_buf then holds
+ * 131072 * 4 / block_size sub-blocks (e.g. 129024 samples) and its Mode A/C noise threshold uses the mean of the sub-block means
+ * (:389-404); this library keeps 131072-sample blocks, so demodulate2400AC decisions near the threshold can differ (Mode S does
+ * not depend on block boundaries).  Not available with dc_filter. */
+int rsb_stream_push_bladerf(rsb_stream *st, const void *buf, size_t bytes, uint32_t block_size, uint32_t decimation, uint32_t *overruns);
 int rsb_stream_flush(rsb_stream *st);
 int rsb_stream_close(rsb_stream *st);   /* flush, then free the stream (not the context) */
 

@@ -96,6 +96,7 @@ SYMBOLS = {
     "rsb_forwarder_push": (C.c_int, [_VP, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_stream_open": (C.c_int, [_VP, C.c_uint32, _VP, _VP, C.POINTER(_VP)]),
     "rsb_stream_push": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint64]),
+    "rsb_stream_push_bladerf": (C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "rsb_stream_flush": (C.c_int, [_VP]),
     "rsb_stream_close": (C.c_int, [_VP]),
     "rsb_merge_by_timestamp": (C.c_int, [_VP, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
@@ -146,6 +147,13 @@ class Stream:
     def push(self, block: np.ndarray, dropped_before: int = 0):
         raw = np.ascontiguousarray(block).view(np.uint8).reshape(-1)
         self.ch._check(self.l.rsb_stream_push(self.h, raw.ctypes.data if raw.size else None, raw.size // self.ch.bps, dropped_before), "rsb_stream_push")
+
+    def push_bladerf(self, buf: np.ndarray, block_size: int, decimation: int = 1) -> int:
+        """One bladeRF transfer buffer (16-byte metadata header per sub-block); returns the number of overrun flags seen."""
+        raw = np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
+        over = C.c_uint32(0)
+        self.ch._check(self.l.rsb_stream_push_bladerf(self.h, raw.ctypes.data, raw.size, block_size, decimation, C.byref(over)), "rsb_stream_push_bladerf")
+        return over.value
 
     def flush(self):
         self.ch._check(self.l.rsb_stream_flush(self.h), "rsb_stream_flush")

@@ -25,6 +25,7 @@ struct rsb_stream {
     uint64_t filled = 0;        // samples staged in h_stage[cur]
     unsigned in_flight = 0;     // batches submitted and not collected
     bool ended = false;         // a short block was pushed
+    uint64_t bladerf_next = 0;  // rsb_stream_push_bladerf: the hardware timestamp the next sub-block should carry (0 = none seen yet)
 };
 
 namespace {
@@ -64,6 +65,31 @@ int submit_staged(rsb_stream *st) {
     st->cur ^= 1;
     // the buffers now current belong to the batch before this one: finished with once that batch is collected
     return st->in_flight == 2 ? collect_one(st) : RSB_OK;
+}
+
+// append samples to the staging buffer, submitting every time it is full (any count: sub-blocks of a framed transfer)
+int stage_samples(rsb_stream *st, const uint8_t *src, uint64_t n) {
+    const uint64_t cap = (uint64_t)st->blocks * kBlock;
+    while (n) {
+        if (st->filled >= cap) {  // an earlier submit failed and left the buffer full
+            st->c->err = "rsb_stream: the staging buffer is full (an earlier push failed)";
+            return RSB_ESTATE;
+        }
+        const uint64_t k = n < cap - st->filled ? n : cap - st->filled;
+        if (src) {
+            std::memcpy(st->h_stage[st->cur] + (size_t)st->filled * st->bps, src, (size_t)k * st->bps);
+            src += (size_t)k * st->bps;
+        } else {
+            std::memset(st->h_stage[st->cur] + (size_t)st->filled * st->bps, 0, (size_t)k * st->bps);  // zero IQ (SC16 formats: magnitude 0)
+        }
+        st->filled += k;
+        n -= k;
+        if (st->filled == cap) {
+            const int rc = submit_staged(st);
+            if (rc != RSB_OK) return rc;
+        }
+    }
+    return RSB_OK;
 }
 
 int drain(rsb_stream *st) {
@@ -160,16 +186,99 @@ int rsb_stream_push(rsb_stream *st, const void *iq_host, uint32_t nsamples, uint
     return st->filled == (uint64_t)st->blocks * kBlock ? submit_staged(st) : RSB_OK;
 }
 
+int rsb_stream_push_bladerf(rsb_stream *st, const void *buf, size_t bytes, uint32_t block_size, uint32_t decimation, uint32_t *overruns) {
+    if (!st || !buf || block_size <= 16 || (block_size - 16) % 4 != 0 || !decimation) return RSB_EINVAL;
+    rsb_ctx *c = st->c;
+    if (c->cfg.input_format != RSB_SC16Q11 && c->cfg.input_format != RSB_SC16) {
+        c->err = "rsb_stream_push_bladerf: the context must take 4-byte samples (SC16Q11 is what the bladeRF delivers)";
+        return RSB_EINVAL;
+    }
+    if (st->ended) {
+        c->err = "rsb_stream_push_bladerf: the stream has ended";
+        return RSB_ESTATE;
+    }
+    ST_TRY(st, hipSetDevice(c->cfg.device));
+    const uint8_t *p = (const uint8_t *)buf;
+    const uint32_t per_block = (block_size - 16) / 4;  // sdr_bladerf.c:335
+    auto rd32 = [](const uint8_t *q) { return (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24; };
+    // Pass 1 over the headers (sdr_bladerf.c:339-378): a wrong magic ends the buffer; a timestamp that is not the expected one
+    // restarts the buffer THERE -- the reference throws away what it had converted of this buffer so far (:370-373).
+    size_t nblocks = 0, first_kept = 0;
+    uint64_t expect = st->bladerf_next, restart_ts = 0;
+    bool restarted = false;
+    uint32_t nover = 0;
+    for (size_t off = 0; off + block_size <= bytes; off += block_size, ++nblocks) {
+        const uint8_t *h = p + off;
+        if (rd32(h) != 0x12344321u) break;
+        const uint64_t ts = (uint64_t)rd32(h + 4) | (uint64_t)rd32(h + 8) << 32;
+        if (rd32(h + 12) & 1u) ++nover;  // BLADERF_META_STATUS_OVERRUN
+        if (expect && ts != expect) {
+            restarted = true;
+            restart_ts = ts;
+            first_kept = nblocks;
+        }
+        expect = ts + (uint64_t)per_block * decimation;
+    }
+    if (overruns) *overruns = nover;
+    if (!nblocks) return RSB_OK;
+    if (!st->bladerf_next) {  // first buffer: the stream's sample 0 is this buffer's first sample, whatever its hardware timestamp
+        st->bladerf_next = ((uint64_t)rd32(p + 4) | (uint64_t)rd32(p + 8) << 32);
+    }
+    if (restarted) {
+        // Samples were lost: the stream position jumps as the hardware timestamp did (message timestamps stay those of the
+        // reference, sampleTimestamp = timestamp * 12e6 / rate / decimation, :382) and decoding starts from a zero carry.  The
+        // library's positions are whole blocks, so it seeks to the block the new position lies in and feeds zeros up to it.
+        if (restart_ts < st->bladerf_next) {
+            c->err = "rsb_stream_push_bladerf: the hardware timestamp went backwards";
+            return RSB_EINVAL;
+        }
+        int rc = submit_staged(st);
+        if (rc == RSB_OK) rc = drain(st);
+        if (rc != RSB_OK) return rc;
+        const uint64_t lost = (restart_ts - st->bladerf_next) / decimation;  // samples between what was staged and the sub-block kept first
+        const uint64_t pos = c->submit_pos + lost;                          // (whatever this buffer held before that sub-block is dropped, as in the reference)
+        rc = rsb_seek(c, pos / kBlock * kBlock, nullptr, 0);
+        if (rc != RSB_OK) return rc;
+        rc = stage_samples(st, nullptr, pos % kBlock);
+        if (rc != RSB_OK) return rc;
+        st->bladerf_next = restart_ts;
+    }
+    for (size_t k = first_kept; k < nblocks; ++k) {
+        const int rc = stage_samples(st, p + k * (size_t)block_size + 16, per_block);
+        if (rc != RSB_OK) return rc;
+    }
+    st->bladerf_next += (uint64_t)(nblocks - first_kept) * per_block * decimation;
+    return RSB_OK;
+}
+
+// everything == false: only the whole blocks that are staged go (a framed source stages sub-blocks of any length, and a batch
+// that is not a whole number of blocks would end the recording); the rest moves to the front of the other staging buffer
+static int flush_impl(rsb_stream *st, bool everything) {
+    ST_TRY(st, hipSetDevice(st->c->cfg.device));
+    const uint64_t whole = st->filled / kBlock * kBlock, rest = everything ? 0 : st->filled - whole;
+    const uint8_t *tail = st->h_stage[st->cur] + (size_t)whole * st->bps;
+    st->filled -= rest;
+    int rc = submit_staged(st);  // flips st->cur (the copy that reads the old buffer does not mind our reading it too)
+    if (rc == RSB_OK) rc = drain(st);
+    if (rest) {
+        if (rc == RSB_OK && whole) {
+            std::memcpy(st->h_stage[st->cur], tail, (size_t)rest * st->bps);
+            st->filled = rest;
+        } else {
+            st->filled += rest;  // nothing was submitted (or it failed): the samples stay where they are
+        }
+    }
+    return rc;
+}
+
 int rsb_stream_flush(rsb_stream *st) {
     if (!st) return RSB_EINVAL;
-    ST_TRY(st, hipSetDevice(st->c->cfg.device));
-    const int rc = submit_staged(st);
-    return rc == RSB_OK ? drain(st) : rc;
+    return flush_impl(st, st->bladerf_next == 0);
 }
 
 int rsb_stream_close(rsb_stream *st) {
     if (!st) return RSB_EINVAL;
-    const int rc = rsb_stream_flush(st);
+    const int rc = flush_impl(st, true);
     if (rc != RSB_OK) {  // leave nothing pending on the context
         size_t n = 0;
         while (st->c->any_pending() && rsb_collect(st->c, st->h_out, st->out_cap, &n) == RSB_OK) {}
