@@ -200,6 +200,12 @@ int rsb_collect(rsb_ctx *ctx, rsb_message *out, size_t cap, size_t *n_out);
  * rsb_collect_wait before reading out[].  Any later rsb_collect* / rsb_reset / rsb_destroy on the context waits by itself.
  * Paths that finish on the host (RSB_FLAG_HOST_REPLAY, Mode A/C lists merged on the host) deliver in _begin; _wait is then a no-op.
  * No counterpart in the reference (readsb.c:883-886 hands messages over one by one). */
+/* Many channels on one GPU: rsb_collect spends most of its time waiting for a short chain of kernels (prune, replay, emit).
+ * rsb_collect_prepare enqueues that chain for the oldest submitted batch on the context's own stream and returns without waiting;
+ * called for every channel before the first rsb_collect, the chains of all channels run side by side and the collects find their
+ * results ready.  Optional (rsb_collect does it otherwise) and a no-op for batches that need the host's step-by-step path.
+ * Filter changes made between prepare and collect (rsb_filter_add*, rsb_filter_expire) apply from the next batch on. */
+int rsb_collect_prepare(rsb_ctx *ctx);
 int rsb_collect_begin(rsb_ctx *ctx, rsb_message *out, size_t cap, size_t *n_out);
 int rsb_collect_wait(rsb_ctx *ctx);
 

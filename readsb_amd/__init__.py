@@ -75,6 +75,7 @@ SYMBOLS = {
     "rsb_collect": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_collect_begin": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_collect_wait": (C.c_int, [_VP]),
+    "rsb_collect_prepare": (C.c_int, [_VP]),
     "rsb_process": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_process_host": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_get_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
@@ -258,6 +259,9 @@ class Channel:
             raise RsbError(f"rsb_collect_begin: {n.value} messages exceed cap {out.size}")
         self._check(rc, "rsb_collect_begin")
         return out[:n.value]
+
+    def collect_prepare(self):
+        self._check(self.l.rsb_collect_prepare(self.h), "rsb_collect_prepare")
 
     def collect_wait(self):
         self._check(self.l.rsb_collect_wait(self.h), "rsb_collect_wait")

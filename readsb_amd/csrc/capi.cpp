@@ -1046,6 +1046,28 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
 
 extern "C" {
 
+int rsb_collect_prepare(rsb_ctx *c) {
+    if (!c) return RSB_EINVAL;
+    if (!c->any_pending()) {
+        c->err = "rsb_collect_prepare: nothing submitted";
+        return RSB_ESTATE;
+    }
+    rsb_slot &nb = c->collect_slot();
+    if (nb.chain_enqueued || !chain_needs_no_host(c, nb)) return RSB_OK;  // (the second case: rsb_collect does it step by step)
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t s = c->replay_stream;
+    HIP_TRY(c, hipStreamWaitEvent(s, nb.ev[3], 0));
+    HIP_TRY(c, hipEventRecord(nb.rev[0], s));
+    if (!nb.pruned) {
+        const int rc = enqueue_prune(c, nb, nb.pending_args, s);
+        if (rc != RSB_OK) return rc;
+    }
+    c->sorted_buf = 0;
+    const int rc = replay_enqueue(c, nb, kept_items_bound(c, nb), true, s);
+    if (rc != RSB_OK) nb.chain_enqueued = false;
+    return rc;
+}
+
 int rsb_collect_wait(rsb_ctx *c) {
     if (!c) return RSB_EINVAL;
     if (c->copy_in_flight) {
