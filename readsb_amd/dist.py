@@ -91,13 +91,30 @@ def shard_scan(ch, start: int, nsamples: int, dev_ptr: int, carry) -> np.ndarray
     return ch.export_adders()
 
 
-def shard_finish(ch, all_adders: np.ndarray, filter_in: np.ndarray | None, cap: int):
-    """steps 2 and 3 on one rank: widen the superset, take over the filter, collect -> (messages, filter to pass on)"""
+def shard_finish(ch, all_adders: np.ndarray, filter_in: np.ndarray | None, cap: int, forward=None):
+    """steps 2 and 3 on one rank: widen the superset, take over the filter, collect -> (messages, filter to pass on).
+    forward(filter): called as soon as the filter is final -- the next rank in the ring waits for nothing else -- which with a
+    channel that has collect_begin / collect_wait is BEFORE this shard's records have crossed PCIe (rsb_collect_begin: the
+    replay has converged and folded its new members into the filter; the record copy is what remains)."""
     ch.superset_add(all_adders)
     if filter_in is not None:
         ch.filter_add_many(np.unique(filter_in))  # one call: the scan of this shard is pending, every add would wait and copy
+    if hasattr(ch, "collect_begin"):
+        buf = getattr(ch, "_shard_out", None)
+        if buf is None or buf.size < cap:  # pinned, or the copy would block inside collect_begin
+            buf = torch.empty(cap * MSG_DTYPE.itemsize, dtype=torch.uint8, pin_memory=torch.cuda.is_available()).numpy().view(MSG_DTYPE)
+            ch._shard_out = buf
+        view = ch.collect_begin(buf[:cap])
+        flt = ch.filter_export()
+        if forward is not None:
+            forward(flt)
+        ch.collect_wait()
+        return view.copy(), flt
     msgs = ch.collect(cap).copy()
-    return msgs, ch.filter_export()
+    flt = ch.filter_export()
+    if forward is not None:
+        forward(flt)
+    return msgs, flt
 
 
 def _all_gather_u32(mine: np.ndarray, device: torch.device) -> np.ndarray:
@@ -157,12 +174,15 @@ def decode_recording_sharded(ch, total_samples: int, segment_samples: int, get_s
         union = _all_gather_u32(adders, device)
         if k < nseg:
             filter_in = _recv_u32((rank - 1) % n, device) if (k >= 1 and n > 1) else None
-            msgs, flt = shard_finish(ch, union, filter_in, cap)
+            def forward(flt, k=k):  # the serial part of the ring ends here: the filter goes on before the records have left the GPU
+                nonlocal pending
+                if k + 1 < nseg and n > 1:
+                    for req, _ in pending:
+                        req.wait()
+                    pending = _isend_u32(flt, (rank + 1) % n, device)
+
+            msgs, _ = shard_finish(ch, union, filter_in, cap, forward)
             mine.append((k, msgs))
-            if k + 1 < nseg and n > 1:
-                for req, _ in pending:
-                    req.wait()
-                pending = _isend_u32(flt, (rank + 1) % n, device)
     for req, _ in pending:
         req.wait()
     return mine
