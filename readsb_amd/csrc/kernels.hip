@@ -844,9 +844,13 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 if (__ballot(hit) != 0) {  // wave-uniform
                     wave_sync();
                     if (hit) {
-#pragma unroll
+                        // (the raw bytes are read again from memory, in a rolled loop: keeping the prefetch registers alive for
+                        // this rare path cost the kernel 11 VGPRs and made it spill)
+                        const int64_t q = (int64_t)(strip * kStrip) - kTileShift - (int64_t)kTrailing;
+                        const uint4 *src0 = (const uint4 *)((const uint8_t *)a.iq + kBps * q) + (int)lane;
+#pragma unroll 1
                         for (int t = 0; t < kPasses; ++t) {
-                            const uint4 raw = pre[t][0];
+                            const uint4 raw = src0[64 * t];
                             uint4 o = ((const uint4 *)W.m)[(int)lane + 64 * t];
                             const uint32_t X[4] = {raw.x, raw.y, raw.z, raw.w};
                             uint32_t O[4] = {o.x, o.y, o.z, o.w};

@@ -1,0 +1,15 @@
+#!/bin/bash
+# one bench line per BASELINE configuration (no CPU baseline): bash tools/bench_configs.sh > gpurun_out/bench_configs.jsonl
+run() { timeout -k 10 300 python -u bench.py --steps 4 --warmup 1 --no-cpu-baseline "$@" 2>/dev/null | tail -1 || exit 1; }
+run
+run --steps-in-flight 1
+run --output beast
+run --format SC16
+run --format SC16Q11
+run --format SC16 --dcfilter
+run --dcfilter
+run --modeac
+run --modeac --fix-bits 2 --dense
+run --modeac --format SC16
+run --channels-per-gpu 32
+run --batches 4 --in-flight 4
