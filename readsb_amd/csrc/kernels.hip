@@ -43,10 +43,10 @@
 #define DBG_FLUSH
 #endif
 #ifndef RSB_RADIAL_DEPTH
-#define RSB_RADIAL_DEPTH 2
+#define RSB_RADIAL_DEPTH 1
 #endif
 #ifndef RSB_SLICE_AHEAD
-#define RSB_SLICE_AHEAD 2
+#define RSB_SLICE_AHEAD 1
 #endif
 #ifndef RSB_LATE_PASSES
 #define RSB_LATE_PASSES 0
