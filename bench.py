@@ -407,7 +407,9 @@ def main() -> int:
             with open(tfile) as f:
                 t = json.load(f)
             # ... of this very build: the file names the kernel source it was measured on
-            if t.get("samples") == n and args.format == "UC8" and not args.dcfilter and t.get("kernel_src_sha256") == kernel_src_sha():
+            # ... and on this workload: one launch over the whole recording, configs[1]
+            same_workload = C == 1 and len(cuts) == 2 and args.format == "UC8" and args.fix_bits == 1 and not (args.dcfilter or args.modeac or args.dense)
+            if t.get("samples") == n and same_workload and t.get("kernel_src_sha256") == kernel_src_sha():
                 traffic = t.get("bytes_per_launch")
         scan_s = float(np.mean(scan_ms)) / 1e3
         scan_bps = 2 if args.dcfilter else bps  # --dcfilter: the scan kernel reads the converter's 16-bit magnitudes

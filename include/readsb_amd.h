@@ -120,7 +120,9 @@ typedef struct rsb_stats {
     uint64_t strong_signal_count;   /* signalLevel > 0.50119 (-3 dBFS) */
     /* how the scan kernel converted its strips of 2768 offsets (diagnostics; no counterpart in the reference) */
     uint64_t general_strips;        /* sample by sample: first / last strips of a batch, unaligned input */
-    uint64_t patched_strips;        /* UC8: strips with samples whose magnitude came from the full 256 x 256 table (DESIGN.md 4) */
+    uint64_t patched_strips;        /* UC8: strips with samples whose magnitude came from the full 256 x 256 table (DESIGN.md 5) */
+    uint64_t split_strips;          /* times a strip was taken again in more parts because one of the kernel's LDS queues overflowed */
+    uint64_t sort_fallbacks;        /* batches whose items had to be sorted (a single pass of 512 offsets overflowed a queue) */
 } rsb_stats;
 
 /* Durations of the last rsb_submit, measured with HIP events on the submit stream. */

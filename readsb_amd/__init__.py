@@ -49,7 +49,7 @@ class Stats(C.Structure):
                 ("modeac_candidates", C.c_uint64),
                 ("signal_power_sum", C.c_double), ("signal_power_count", C.c_uint64), ("noise_power_sum", C.c_double),
                 ("noise_power_count", C.c_uint64), ("peak_signal_power", C.c_double), ("strong_signal_count", C.c_uint64),
-                ("general_strips", C.c_uint64), ("patched_strips", C.c_uint64)]
+                ("general_strips", C.c_uint64), ("patched_strips", C.c_uint64), ("split_strips", C.c_uint64), ("sort_fallbacks", C.c_uint64)]
 
 
 class Timing(C.Structure):

@@ -873,7 +873,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         // the sequential half: on the device, unless asked otherwise or the device path declines the batch
         if (!c->run_modes) {
             on_device = 1;  // nothing to replay: a Mode A/C only pass of the drop-in
-            std::memset(cnt + kCntChanged, 0, (kCntCount - kCntChanged) * sizeof(uint32_t));
+            std::memset(cnt + kCntChanged, 0, (kCntGeneralStrips - kCntChanged) * sizeof(uint32_t));
             c->h_blk_counts.assign(nblocks + 1, 0);
         } else if (!c->host_replay_only && !a.emit_dead && !a.keep_all) {
             // records wanted and nothing to interleave: the list can leave in parts while it is still being written
@@ -1012,7 +1012,9 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     st.gated_offsets += cnt[kCntGated];
     st.general_strips += cnt[kCntGeneralStrips];
     st.patched_strips += cnt[kCntFixedStrips];
-    if (std::getenv("RSB_VERBOSE")) std::fprintf(stderr, "readsb_amd: %u strips converted on the general path, %u patched from the full UC8 table, %u gated offsets\n", cnt[kCntGeneralStrips], cnt[kCntFixedStrips], cnt[kCntGated]);
+    st.split_strips += cnt[kCntSplitStrips];
+    st.sort_fallbacks = c->sort_fallbacks;
+    if (std::getenv("RSB_VERBOSE")) std::fprintf(stderr, "readsb_amd: %u strips converted on the general path, %u patched from the full UC8 table, %u split, %u gated offsets\n", cnt[kCntGeneralStrips], cnt[kCntFixedStrips], cnt[kCntSplitStrips], cnt[kCntGated]);
     st.live_candidates += cnt[kCntItemsTotal];
     st.survivors += on_device ? cnt[kCntAccepted] : cnt[kCntSurvivors];
     st.modeac_candidates += cnt[kCntAc];

@@ -746,24 +746,24 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     WaveShared &W = sh.w[wave];
     const uint32_t gwave = blockIdx.x * kScanWaves + wave;
     ItemRec *region = a.items + (size_t)gwave * a.item_region;
-    uint32_t nitems = 0, gated_total = 0, slow_total = 0, general_strips = 0, fixed_strips = 0;  // wave-uniform
-    const uint64_t nstrips = (a.n + kTileShift + kStrip - 1) / kStrip;
+    uint32_t nitems = 0, gated_total = 0, slow_total = 0, general_strips = 0, fixed_strips = 0, split_strips = 0;  // wave-uniform
+    const uint32_t nstrips = (uint32_t)((a.n + kTileShift + kStrip - 1) / kStrip);  // (2^32 strips = 10^13 samples: beyond any HBM)
     // The raw IQ of a strip is fetched one strip ahead into registers (8 x 16 bytes per lane and raw vector), so
     // the HBM latency of strip k + 1 hides behind the gate / slicing stages of strip k.
     constexpr bool kVecFmt = true;
     constexpr int kRawVecs = (FMT == kFmtUC8 || FMT == kFmtMag16) ? 1 : 2;  // 16-byte loads per 8 samples
     constexpr int kBps = 2 * kRawVecs;                                       // bytes per sample
     uint4 pre[kPasses][kRawVecs];
-    auto interior = [&](uint64_t strip) {  // wave-uniform: every chunk of the strip is aligned raw IQ (all strips but the first and the last few)
-        const int64_t q = (int64_t)(strip * kStrip) - kTileShift - (int64_t)kTrailing;
+    auto interior = [&](uint32_t strip) {  // wave-uniform: every chunk of the strip is aligned raw IQ (all strips but the first and the last few)
+        const int64_t q = (int64_t)((uint64_t)strip * kStrip) - kTileShift - (int64_t)kTrailing;
         return kVecFmt && a.iq_aligned && strip < nstrips && q >= 0 && q + kRegion <= (int64_t)a.n;
     };
     // The last kLatePasses chunks of a strip are fetched at the top of the strip itself (they are converted last, behind the table
     // reads of the others): 4 registers per raw vector and pass that the slicing stage of the strip before does not have to carry.
     constexpr int kLatePasses = RSB_LATE_PASSES;
-    auto fetch_passes = [&](uint64_t strip, int t_lo, int t_hi) {
+    auto fetch_passes = [&](uint32_t strip, int t_lo, int t_hi) {
         if (!interior(strip)) return;
-        const int64_t q = (int64_t)(strip * kStrip) - kTileShift - (int64_t)kTrailing;
+        const int64_t q = (int64_t)((uint64_t)strip * kStrip) - kTileShift - (int64_t)kTrailing;
         const uint4 *src0 = (const uint4 *)((const uint8_t *)a.iq + kBps * q) + kRawVecs * (int)lane;
 #pragma unroll
         for (int t = 0; t < kPasses; ++t)
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 for (int r = 0; r < kRawVecs; ++r) pre[t][r] = src0[kRawVecs * 64 * t + r];
             }
     };
-    auto prefetch = [&](uint64_t strip) { fetch_passes(strip, 0, kPasses - kLatePasses); };
+    auto prefetch = [&](uint32_t strip) { fetch_passes(strip, 0, kPasses - kLatePasses); };
     uint32_t lut_min = 0x7fff7fffu;  // UC8: packed minimum of the strip's table reads
     auto direct_chunk = [&](int t) {
         if constexpr (FMT == kFmtUC8) {
@@ -788,13 +788,14 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     // Every wavefront takes a CONTIGUOUS run of strips (a.strips_per_wave of them), in ascending order: its item region then is
     // one sorted run of the batch's items, the regions follow each other in stream order, and the prune that comes next only
     // has to compact them in place of a global sort.
-    const uint64_t strip_step = 1;
-    const uint64_t strip_lo = (uint64_t)gwave * a.strips_per_wave;
-    const uint64_t strip_hi = strip_lo + a.strips_per_wave < nstrips ? strip_lo + a.strips_per_wave : nstrips;
+    const uint32_t strip_step = 1;
+    const uint64_t first = (uint64_t)gwave * a.strips_per_wave;
+    const uint32_t strip_lo = first < nstrips ? (uint32_t)first : nstrips;
+    const uint32_t strip_hi = first + a.strips_per_wave < nstrips ? (uint32_t)(first + a.strips_per_wave) : nstrips;
     if (RSB_PREFETCH_EARLY && strip_lo < strip_hi) prefetch(strip_lo);
     DBG_DECL
-    for (uint64_t strip = strip_lo; strip < strip_hi; strip += strip_step) {
-        const int64_t s0 = (int64_t)(strip * kStrip) - kTileShift;  // S index of m[0]
+    for (uint32_t strip = strip_lo; strip < strip_hi; strip += strip_step) {
+        const int64_t s0 = (int64_t)((uint64_t)strip * kStrip) - kTileShift;  // S index of m[0]
         if (!RSB_PREFETCH_EARLY) prefetch(strip);
         if (kLatePasses) fetch_passes(strip, kPasses - kLatePasses, kPasses);
         wave_sync();
@@ -846,7 +847,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                     if (hit) {
                         // (the raw bytes are read again from memory, in a rolled loop: keeping the prefetch registers alive for
                         // this rare path cost the kernel 11 VGPRs and made it spill)
-                        const int64_t q = (int64_t)(strip * kStrip) - kTileShift - (int64_t)kTrailing;
+                        const int64_t q = (int64_t)((uint64_t)strip * kStrip) - kTileShift - (int64_t)kTrailing;
                         const uint4 *src0 = (const uint4 *)((const uint8_t *)a.iq + kBps * q) + (int)lane;
 #pragma unroll 1
                         for (int t = 0; t < kPasses; ++t) {
@@ -882,16 +883,13 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             for (int t = 0; t < kPasses; ++t) take_chunk(t, ((const uint4 *)W.m)[(int)lane + 64 * t]);
         }
         edge_accumulate(prev, from_next_lane(lane == 0 ? 0u : prev.x), acc);  // chunk 511 has no successor: not a scan offset
-        if (RSB_PREFETCH_EARLY == 1 && strip + 1 < strip_hi) prefetch(strip + 1);
+        if (RSB_PREFETCH_EARLY && strip + 1 < strip_hi) prefetch(strip + 1);
         wave_sync();
         DBG_STAGE(0) DBG_COUNT(0, 1)
-        if (a.stage_limit < 2) {
-            if (RSB_PREFETCH_EARLY == 2 && strip + 1 < strip_hi) prefetch(strip + 1);
-            continue;
-        }
+        if (a.stage_limit < 2) continue;
 
         // ---- demod_2400.c:109-155, edge patterns only, bit-parallel: 4 offsets x 8 passes per lane and instruction
-        uint32_t neq = 0;  // wave-uniform
+        uint32_t E[2];  // per lane: the candidates of its chunks, 4 offsets x kPasses passes per word
         {
             uint32_t L[5], G[5];
             L[0] = __builtin_amdgcn_perm(acc[1], acc[0], 0x07050301u);  // samples 0..3 of the lane's chunks
@@ -908,33 +906,53 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             // below chunk kStrip / 8; the bits below the first pass are shifted-in leftovers of next_chunk()
             constexpr uint32_t kPassBits = ((0xffu << (8 - kPasses)) & 0xffu) * 0x01010101u;
             const uint32_t live = lane < (uint32_t)(kStrip / 8 - 64 * (kPasses - 1)) ? kPassBits : (kPassBits & 0x7f7f7f7fu);
-            uint32_t E[2] = {edge_patterns<0>(L, G) & live, edge_patterns<1>(L, G) & live};
+            E[0] = edge_patterns<0>(L, G) & live;
+            E[1] = edge_patterns<1>(L, G) & live;
+        }
+        // The stages below keep their candidates in LDS queues of fixed size.  A strip that overflows one (strong bursts: a few
+        // strips per Gsample) is taken again in parts -- 2, 3, then kPasses runs of passes, i.e. ranges of 512 consecutive offsets
+        // and more, in ascending order -- each part with the whole queues to itself, so the wavefront's items still leave sorted
+        // (the ordered prune depends on it; one item on the per-thread path sends the whole batch through the radix sort).  Only
+        // when single passes overflow do the per-thread paths run.  Nothing of a strip is written before its last stage, and
+        // what that writes (items, adder marks) is written again identically.
+        // The code of the stages exists twice: once for the whole strip with nothing of the splitting in it (every strip runs
+        // it first; folding the general case into that one cost 4 % of the kernel), once for a strip in parts.
+        uint32_t nparts = 1;  // wave-uniform
+        const uint32_t nitems0 = nitems;
+        uint32_t gated_strip = 0, slow_strip = 0;
+        auto attempt = [&](auto whole_strip) -> bool {  // -> a queue overflowed: take the strip again in more parts
+        constexpr bool kWhole = decltype(whole_strip)::value;
+        nitems = nitems0;
+        gated_strip = slow_strip = 0;
+        const uint32_t np = kWhole ? 1u : nparts;
+        for (uint32_t part = 0; part < np; ++part) {
+        const bool last_resort = !kWhole && np >= (uint32_t)kPasses;
+        const uint32_t p_lo = part * kPasses / np, p_hi = (part + 1) * kPasses / np;
+        const uint32_t part_bits = kWhole ? 0xffffffffu : (((1u << p_hi) - (1u << p_lo)) << (8 - kPasses)) * 0x01010101u;
+        uint32_t neq = 0;  // wave-uniform
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                uint32_t e = E[q];
-                for (;;) {
-                    const uint64_t bm = __ballot(e != 0);
-                    if (!bm) break;
-                    if (e) {
-                        const uint32_t b = (uint32_t)__builtin_ctz(e);
-                        e &= e - 1;
-                        const uint32_t j = (((b & 7u) - (8 - kPasses)) << 9) | (lane << 3) | (4u * q + (b >> 3));  // pass, lane, sample of the chunk
-                        const uint32_t pos = neq + lanes_below(bm);
-                        if (pos < (uint32_t)kEdgeCap)
-                            W.eq[pos] = (uint16_t)j;
-                        else
-                            slow_offset(a, W.m, j, s0);
-                    }
-                    neq += __popcll(bm);
+        for (int q = 0; q < 2; ++q) {
+            uint32_t e = E[q] & part_bits;
+            for (;;) {
+                const uint64_t bm = __ballot(e != 0);
+                if (!bm) break;
+                if (e) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(e);
+                    e &= e - 1;
+                    const uint32_t j = (((b & 7u) - (8 - kPasses)) << 9) | (lane << 3) | (4u * q + (b >> 3));  // pass, lane, sample of the chunk
+                    const uint32_t pos = neq + lanes_below(bm);
+                    if (pos < (uint32_t)kEdgeCap)
+                        W.eq[pos] = (uint16_t)j;
+                    else if (last_resort)
+                        slow_offset(a, W.m, j, s0);
                 }
+                neq += __popcll(bm);
             }
         }
+        if (neq > (uint32_t)kEdgeCap && !last_resort) return true;
         wave_sync();
         DBG_STAGE(1) DBG_COUNT(4, neq)
-        if (a.stage_limit < 3) {
-            if (RSB_PREFETCH_EARLY == 2 && strip + 1 < strip_hi) prefetch(strip + 1);
-            continue;
-        }
+        if (a.stage_limit < 3) continue;
 
         // ---- the whole gate (:109-172) on the edge candidates; survivors go to the gated queue
         uint32_t ngated = 0;  // wave-uniform
@@ -958,7 +976,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 }
                 if (pos < (uint32_t)kGateCap) {
                     W.gq[pos] = (uint16_t)j;
-                } else {
+                } else if (last_resort) {
                     for (int p = 0; p < 5; ++p) slow_item(a, &W.m[j + 19], g, p, a.tab.crc_bytes);
                 }
             }
@@ -966,13 +984,11 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             ngated += __popcll(pm);
         }
         wave_sync();
-        gated_total += ngated;
+        if (ngated > (uint32_t)kGateCap && !last_resort) return true;
+        gated_strip += ngated;
         DBG_STAGE(2) DBG_COUNT(1, (neq + 63) / 64)
-        if (ngated > (uint32_t)kGateCap) slow_total += ngated - kGateCap;
-        if (a.stage_limit < 4) {
-            if (RSB_PREFETCH_EARLY == 2 && strip + 1 < strip_hi) prefetch(strip + 1);
-            continue;
-        }
+        if (ngated > (uint32_t)kGateCap) slow_strip += ngated - kGateCap;
+        if (a.stage_limit < 4) continue;
         const uint32_t ngq = min(ngated, (uint32_t)kGateCap);
         // The gated offsets in ascending order (the edge queue is filled bit by bit, not offset by offset): rank by counting, the
         // queue is short (about 25 entries).  From here on everything keeps that order -- (offset, phase) pairs, the frame list,
@@ -1019,21 +1035,18 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
                 const uint32_t pos = nlist + lanes_below(cm);
                 if (pos < (uint32_t)kListCap) {
                     W.fl[pos] = (uint16_t)(i | (cls << 15));
-                } else {
+                } else if (last_resort) {
                     slow_item(a, &W.m[j + 19], (uint32_t)(s0 + j), (int)phase, a.tab.crc_bytes);
                 }
             }
             nlist += __popcll(cm);
         }
-        if (nlist > (uint32_t)kListCap) slow_total += nlist - kListCap;
+        if (nlist > (uint32_t)kListCap && !last_resort) return true;
+        if (nlist > (uint32_t)kListCap) slow_strip += nlist - kListCap;
         wave_sync();
         DBG_STAGE(3) DBG_COUNT(2, (5 * ngq + 63) / 64)
-        if (a.stage_limit < 5) {
-            if (RSB_PREFETCH_EARLY == 2 && strip + 1 < strip_hi) prefetch(strip + 1);
-            continue;
-        }
+        if (a.stage_limit < 5) continue;
 
-        if (RSB_PREFETCH_EARLY == 2 && strip + 1 < strip_hi) prefetch(strip + 1);  // the slicing stage (~45 % of a strip's time) covers the HBM latency
         // ---- one lane per frame: 12 (56 bits) or 23 (112 bits) groups of five bits
         const uint32_t nfl = min(nlist, (uint32_t)kListCap);
         for (uint32_t cb = 0; cb < nfl; cb += 64) {
@@ -1133,6 +1146,18 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             nitems += __popcll(em);
         }
         DBG_STAGE(4) DBG_COUNT(5, nfl)
+        }  // parts of the strip
+        return false;
+        };
+        bool redo = attempt(std::true_type{});
+        while (redo) {
+            wave_sync();
+            nparts = nparts == 1 ? 2u : (nparts == 2 && kPasses > 3 ? 3u : (uint32_t)kPasses);
+            split_strips += 1;
+            redo = attempt(std::false_type{});
+        }
+        gated_total += gated_strip;
+        slow_total += slow_strip;
     }
     DBG_FLUSH
     if (lane == 0) {
@@ -1141,6 +1166,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         if (slow_total) atomicAdd(&a.counters[kCntSlowPath], slow_total);
         if (general_strips) atomicAdd(&a.counters[kCntGeneralStrips], general_strips);
         if (fixed_strips) atomicAdd(&a.counters[kCntFixedStrips], fixed_strips);
+        if (split_strips) atomicAdd(&a.counters[kCntSplitStrips], split_strips);
     }
 }
 

@@ -42,9 +42,10 @@ enum : int {
     kCntAccE2,
     kCntGeneralStrips, // scan: strips converted sample by sample (first / last strips, unaligned input)
     kCntFixedStrips,   // scan, UC8: strips with samples whose magnitude the radial table cannot hold (patched from the full table)
-    kCntCount = 16,
-    // RSB_STAGE_CLOCKS builds only: per-stage wave time of the scan kernel (s_memtime ticks >> 4) and work counts
-    kDbgClkConvert = 16, kDbgClkEdge, kDbgClkGate, kDbgClkDf, kDbgClkSlice, kDbgStrips, kDbgGateBatches, kDbgDfBatches, kDbgSliceBatches,
+    kCntSplitStrips,   // scan: times a strip was taken again in more parts because an LDS queue overflowed
+    kCntCount = 20,
+    // debug builds (RSB_STAGE_CLOCKS) and ablation runs only
+    kDbgClkConvert = 20, kDbgClkEdge, kDbgClkGate, kDbgClkDf, kDbgClkSlice, kDbgStrips, kDbgGateBatches, kDbgDfBatches, kDbgSliceBatches,
     kDbgEdgeCands, kDbgFrames, kDbgLongFrames,
     kCntAlloc = 32
 };

@@ -536,3 +536,25 @@ def test_collect_in_two_halves(built):
         for k in range(len(want)):
             assert first_mismatch(want[k].view(REC_DTYPE), got[k].view(REC_DTYPE)) is None
         ch.close()
+
+
+@pytest.mark.parametrize("fmt", ["SC16", "UC8"])
+def test_overflowing_strips_are_split_not_sorted(fmt, built):
+    """k_scan's stages keep their candidates in fixed LDS queues (256 edge candidates, 128 gated offsets, 128 frames per strip of
+    2768 offsets).  Strong overlapping bursts overflow them; such a strip is taken again in 2, 3, 6 parts, every part with the
+    whole queues, so the items still leave in order and the batch stays on the ordered prune (one item on the per-thread path
+    used to send the whole batch through the radix sort: 1 ms per Gsample on the SC16 benchmark recording)."""
+    from readsb_amd.synth import Scenario
+
+    iq = generate(Scenario(3 << 20, seed=51, fmt=fmt, frames_per_sec=9000, amp_lo=0.3, amp_hi=0.9, noise_lsb=4.0))
+    want, wst = Oracle(fmt=fmt, nfix=1).run_stream(iq)
+    assert want.size > 300
+    ch = readsb_amd.Channel(fmt=fmt, fix_bits=1, max_batch_samples=iq.shape[0], queue_div=4)
+    got = ch.process_host(iq, cap=want.size + 1024)
+    assert first_mismatch(want, got.view(REC_DTYPE)) is None
+    st = ch.stats()
+    assert st["demod_accepted"] == [wst["accepted0"], wst["accepted1"], wst["accepted2"]]
+    assert st["split_strips"] > 0, "the recording no longer overflows a queue: make it denser"
+    assert st["sort_fallbacks"] == 0
+    assert ch.timing()["replay_on_device"] == 1
+    ch.close()
