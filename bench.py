@@ -150,6 +150,8 @@ def main() -> int:
     ap.add_argument("--steps-in-flight", type=int, default=2, choices=(1, 2),
                     help="2: step k + 1 (its own receiver channel) is submitted before step k is collected, so the replay / copy tail of one "
                          "recording runs beside the scan of the next; 1: strictly one step at a time")
+    ap.add_argument("--fence", type=int, default=1, choices=(0, 1),
+                    help="with two steps in flight: queue the next step's scan behind this step's chain on the device (rsb_collect_fence)")
     ap.add_argument("--scan-workgroups", type=int, default=-1, help="rsb_config.scan_workgroups: CUs the persistent scan kernel takes; -1 = all with one batch, "
                     "224 with several (one CU per shader engine stays free for the replay kernels of the batch before)")
     ap.add_argument("--output", choices=("records", "beast", "raw"), default="records",
@@ -321,11 +323,21 @@ def main() -> int:
             c, o = chans[k % 2], chans[(k + 1) % 2]
             if k > 0:
                 o.collect_wait()               # step k - 1's records are in host memory (their copy ran beside step k's scan)
-            if k + 1 < count:
-                o.reset()                      # the other channel's next recording starts cold; done while step k's scan runs
-            out = c.collect_begin(bufs[k % 2])  # waits for step k's scan, prune, replay and emit; its copy is under way
-            if k + 1 < count:
-                o.submit(base, nc, stream)
+            if args.fence:
+                # step k's chain goes onto its stream now, and step k + 1's scan is queued behind it ON THE DEVICE: the GPU goes
+                # from emit k to scan k + 1 without waiting for the host to notice that step k is done
+                c.collect_prepare()
+                if k + 1 < count:
+                    o.reset()
+                    c.collect_fence(stream)
+                    o.submit(base, nc, stream)
+                out = c.collect_begin(bufs[k % 2])
+            else:
+                if k + 1 < count:
+                    o.reset()                      # the other channel's next recording starts cold; done while step k's scan runs
+                out = c.collect_begin(bufs[k % 2])  # waits for step k's scan, prune, replay and emit; its copy is under way
+                if k + 1 < count:
+                    o.submit(base, nc, stream)
             if tm is not None:
                 t = c.timing()
                 for key in keys:

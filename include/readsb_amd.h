@@ -208,6 +208,12 @@ int rsb_collect(rsb_ctx *ctx, rsb_message *out, size_t cap, size_t *n_out);
  * results ready.  Optional (rsb_collect does it otherwise) and a no-op for batches that need the host's step-by-step path.
  * Filter changes made between prepare and collect (rsb_filter_add*, rsb_filter_expire) apply from the next batch on. */
 int rsb_collect_prepare(rsb_ctx *ctx);
+/* Device-side ordering without the host: work enqueued on `stream` after this call starts only when the chain that
+ * rsb_collect_prepare put on the context's own stream has finished (without a prepared chain: when the batch's scan has).  For a
+ * caller that wants the NEXT scan -- of this or another context; a scan takes every CU and nothing runs beside it -- queued
+ * behind this batch's prune / replay / emit before the host has even looked at the results:
+ *   rsb_submit(A, ..., s); rsb_collect_prepare(A); rsb_collect_fence(A, s); rsb_submit(B, ..., s); rsb_collect_begin(A, ...); ... */
+int rsb_collect_fence(rsb_ctx *ctx, void *stream);
 int rsb_collect_begin(rsb_ctx *ctx, rsb_message *out, size_t cap, size_t *n_out);
 int rsb_collect_wait(rsb_ctx *ctx);
 

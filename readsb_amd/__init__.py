@@ -76,6 +76,7 @@ SYMBOLS = {
     "rsb_collect_begin": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_collect_wait": (C.c_int, [_VP]),
     "rsb_collect_prepare": (C.c_int, [_VP]),
+    "rsb_collect_fence": (C.c_int, [_VP, _VP]),
     "rsb_process": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_process_host": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_get_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
@@ -262,6 +263,9 @@ class Channel:
 
     def collect_prepare(self):
         self._check(self.l.rsb_collect_prepare(self.h), "rsb_collect_prepare")
+
+    def collect_fence(self, stream: int = 0):
+        self._check(self.l.rsb_collect_fence(self.h, stream), "rsb_collect_fence")
 
     def collect_wait(self):
         self._check(self.l.rsb_collect_wait(self.h), "rsb_collect_wait")

@@ -1070,6 +1070,19 @@ int rsb_collect_prepare(rsb_ctx *c) {
     return rc;
 }
 
+int rsb_collect_fence(rsb_ctx *c, void *stream) {
+    if (!c) return RSB_EINVAL;
+    if (!c->any_pending()) {
+        c->err = "rsb_collect_fence: nothing submitted";
+        return RSB_ESTATE;
+    }
+    rsb_slot &nb = c->collect_slot();
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    // behind the prepared chain's last kernel and readbacks; without a prepared chain, behind the batch's scan
+    HIP_TRY(c, hipStreamWaitEvent((hipStream_t)stream, nb.chain_enqueued ? nb.rev[2] : nb.ev[3], 0));
+    return RSB_OK;
+}
+
 int rsb_collect_wait(rsb_ctx *c) {
     if (!c) return RSB_EINVAL;
     if (c->copy_in_flight) {

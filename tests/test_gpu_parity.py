@@ -558,3 +558,35 @@ def test_overflowing_strips_are_split_not_sorted(fmt, built):
     assert st["sort_fallbacks"] == 0
     assert ch.timing()["replay_on_device"] == 1
     ch.close()
+
+
+def test_prepare_and_fence_order_the_next_scan_on_the_device(built):
+    """rsb_collect_prepare + rsb_collect_fence: batch k's chain is enqueued early and batch k + 1's scan is queued behind it on the
+    caller's stream without a host round trip (bench.py's default loop, there with two channels).  Same lists as plain collects."""
+    import torch
+
+    sc, kw = SCENARIOS["dense_fix2_ac"]
+    iq = generate(sc)
+    nb = 3 * 131072
+    cuts = list(range(0, iq.shape[0], nb)) + [iq.shape[0]]
+    dev = torch.from_numpy(iq).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    want = []
+    ref = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], max_batch_samples=nb)
+    for a, b in zip(cuts, cuts[1:]):
+        ref.submit(dev.data_ptr() + 2 * a, b - a, stream)
+        want.append(ref.collect(cap=1 << 15).copy())
+    ref.close()
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], max_batch_samples=nb)
+    buf = torch.empty((1 << 15) * 56, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE)
+    ch.submit(dev.data_ptr(), cuts[1], stream)
+    for k in range(len(want)):
+        ch.collect_prepare()
+        ch.collect_prepare()  # a second call changes nothing
+        if k + 1 < len(want):
+            ch.collect_fence(stream)
+            ch.submit(dev.data_ptr() + 2 * cuts[k + 1], cuts[k + 2] - cuts[k + 1], stream)
+        out = ch.collect_begin(buf)
+        ch.collect_wait()
+        assert first_mismatch(want[k].view(REC_DTYPE), out.view(REC_DTYPE)) is None
+    ch.close()
