@@ -92,6 +92,8 @@ struct rsb_ctx {
     std::vector<uint64_t> h_blk_sums;
     static constexpr uint32_t kPinAdders = 1024;
     uint32_t *d_addr_upload = nullptr;
+    uint32_t *h_addr_upload = nullptr;    // pinned twin of d_addr_upload: the filter mirror goes up without a host wait
+    hipEvent_t addr_upload_done = nullptr; // the last upload from h_addr_upload has been read
     uint32_t out_cap = 0;
     uint32_t *d_wire_off = nullptr;  // rsb_collect_wire: byte offset per message (grown on demand)
     uint8_t *d_wire_out = nullptr;   // ... and the encoded stream
