@@ -468,29 +468,6 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // set bits of
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
-__device__ __forceinline__ void uc8_addr(uint32_t x, uint32_t &a0, uint32_t &a1) {
-    // two UC8 samples (I0 Q0 I1 Q1) -> the byte addresses of their entries in the folded 128 x 128 table.
-    // |v - 127.5| - 0.5 per byte is v ^ 0x80 (v >= 128) or v ^ 0x7f; the entry lies at 2 fI + 256 fQ, with fQ's
-    // low bits XOR-ed into the bank bits (small signals otherwise hit few banks)
-    const uint32_t t = (x >> 7) & 0x01010101u;
-    const uint32_t f = x ^ (0x7f7f7f7fu + t);
-    const uint32_t sw = (f >> 6) & 0x007c007cu;
-    a0 = ((f & 0xffffu) + (f & 0xffu)) ^ (sw & 0xffffu);
-    a1 = ((f >> 16) + ((f >> 16) & 0xffu)) ^ (sw >> 16);
-}
-__device__ __forceinline__ uint4 uc8_chunk(const uint4 x, const uint16_t *lut) {  // 8 samples -> 8 biased magnitudes
-    uint32_t a[8];
-    uc8_addr(x.x, a[0], a[1]);
-    uc8_addr(x.y, a[2], a[3]);
-    uc8_addr(x.z, a[4], a[5]);
-    uc8_addr(x.w, a[6], a[7]);
-    const uint8_t *b = (const uint8_t *)lut;
-    uint32_t v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = *(const uint16_t *)(b + a[k]);  // all eight lookups in flight together
-    return make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
-}
-
 // 8 UC8 samples -> 8 biased magnitudes through the radial table (ScanShared::lut), in two halves so that the table reads of
 // one chunk fly while the previous chunk is worked on.  The reads are written out by hand to control exactly that; the
 // compiler does not count them in its s_waitcnt bookkeeping, so the waits are ours: LDS operations of a wavefront complete
@@ -527,6 +504,56 @@ __device__ __forceinline__ uint4 radial_take(RadialChunk &c, uint32_t &mn) {
     for (int k = 0; k < 4; ++k) {
         o[k] = __builtin_amdgcn_perm(c.hi[k], c.lo[k], 0x07060100u);
         mn = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(short2v, mn), __builtin_bit_cast(short2v, o[k])));
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// The radial table for a whole workgroup (k_scan's prologue in one place): lut[P / 2] = magnitude ^ bias_xor, entries that two
+// byte pairs disagree on = the sentinel (magnitude 0).  Contains workgroup barriers.
+__device__ __forceinline__ void fill_radial_table(uint16_t *lut, const uint16_t *full, uint32_t bias_xor, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid; i < (uint32_t)kRadialEntries; i += nthreads) lut[i] = (uint16_t)bias_xor;
+    __syncthreads();
+    for (uint32_t i = tid; i < 16384; i += nthreads) {
+        const uint32_t vi = 128 + (i & 127), vq = 128 + (i >> 7);
+        lut[(vi * (255 - vi) + vq * (255 - vq)) >> 1] = (uint16_t)(full[(vq << 8) | vi] ^ bias_xor);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 16384; i += nthreads) {
+        const uint32_t vi = 128 + (i & 127), vq = 128 + (i >> 7), k = (vi * (255 - vi) + vq * (255 - vq)) >> 1;
+        if (lut[k] != (uint16_t)(full[(vq << 8) | vi] ^ bias_xor)) lut[k] = (uint16_t)bias_xor;
+    }
+    __syncthreads();
+}
+
+// 8 UC8 samples -> 8 magnitudes (^ bias_xor) through the radial table, exact on the spot: a chunk that meets a sentinel entry
+// takes those samples from the full table in global memory (the kernels that convert a few hundred samples per lane; k_scan
+// checks once per strip instead)
+template <uint32_t BIAS_XOR>
+__device__ __forceinline__ uint4 uc8_chunk_radial_exact(const uint4 x, uint32_t lut_lds, const uint16_t *full) {
+    using lds_u16 = const __attribute__((address_space(3))) uint16_t;
+    const uint32_t X[4] = {x.x, x.y, x.z, x.w};
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t nx = ~X[k];
+        const uint32_t lo = *(lds_u16 *)(uintptr_t)__builtin_amdgcn_udot4(X[k] & 0x0000ffffu, nx, lut_lds, false);
+        const uint32_t hi = *(lds_u16 *)(uintptr_t)__builtin_amdgcn_udot4(X[k] & 0xffff0000u, nx, lut_lds, false);
+        o[k] = lo | (hi << 16);
+    }
+    // the sentinel is the smallest value a table entry can have (magnitude 0; biased: the smallest int16): one packed minimum
+    uint32_t mn = o[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        mn = BIAS_XOR ? __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(short2v, mn), __builtin_bit_cast(short2v, o[k])))
+                      : __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2v, mn), __builtin_bit_cast(ushort2v, o[k])));
+    const bool hit = (mn & 0xffffu) == BIAS_XOR || (mn >> 16) == BIAS_XOR;
+    if (__builtin_expect(hit, 0)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((o[k] & 0xffffu) == BIAS_XOR) o[k] = (o[k] & 0xffff0000u) | (full[X[k] & 0xffffu] ^ BIAS_XOR);
+            if ((o[k] >> 16) == BIAS_XOR) o[k] = (o[k] & 0xffffu) | ((full[X[k] >> 16] ^ BIAS_XOR) << 16);
+        }
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
@@ -702,20 +729,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     ScanShared &sh = *reinterpret_cast<ScanShared *>(scan_lds);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform: SGPR
 
-    if (FMT == kFmtUC8) {
-        // one quadrant of the byte pairs covers every P (the table is symmetric under v -> 255 - v, as the folded table assumed)
-        for (uint32_t i = tid; i < (uint32_t)kRadialEntries; i += kScanThreads) sh.lut[i] = (uint16_t)kRadialSentinel;
-        __syncthreads();
-        for (uint32_t i = tid; i < 16384; i += kScanThreads) {
-            const uint32_t vi = 128 + (i & 127), vq = 128 + (i >> 7);
-            sh.lut[(vi * (255 - vi) + vq * (255 - vq)) >> 1] = (uint16_t)(a.tab.uc8_lut[(vq << 8) | vi] ^ kBias);
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < 16384; i += kScanThreads) {  // byte pairs that share a P and not a magnitude: no entry for that P
-            const uint32_t vi = 128 + (i & 127), vq = 128 + (i >> 7), k = (vi * (255 - vi) + vq * (255 - vq)) >> 1;
-            if (sh.lut[k] != (uint16_t)(a.tab.uc8_lut[(vq << 8) | vi] ^ kBias)) sh.lut[k] = (uint16_t)kRadialSentinel;
-        }
-    }
+    if (FMT == kFmtUC8) fill_radial_table(sh.lut, a.tab.uc8_lut, kBias, tid, kScanThreads);  // (one quadrant of the byte pairs covers every P)
     for (uint32_t i = tid; i < 2 * kBloomWords; i += kScanThreads) sh.bloom[0][i] = 0;
     for (uint32_t i = tid; i < 160; i += kScanThreads) {
         const uint32_t row = i >> 4, e = i & 15;
@@ -1677,7 +1691,7 @@ constexpr int kEmitWaves = 8;   // (16 capped the kernel at 128 VGPRs and made i
 constexpr int kEmitTrios = 12;       // 3 chunks = 12 rows (24 samples) = 2 groups of five bits per step; 24 groups >= 23
 
 struct __attribute__((aligned(16))) EmitShared {
-    uint16_t lut[16384];
+    uint16_t lut[kRadialEntries];
     uint32_t coef[10][16];
     uint32_t gsyn[(12 + 24) * 32];  // + one zero row: the 24th step
     uint32_t rec[kEmitWaves][64 * 14];  // per wavefront: its 64 records, so that they leave as contiguous 16-byte stores
@@ -1690,11 +1704,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
     extern __shared__ __attribute__((aligned(16))) unsigned char emit_lds[];  // 66 KB: over the static limit
     EmitShared &sh = *reinterpret_cast<EmitShared *>(emit_lds);
     constexpr uint32_t kT = 64 * kEmitWaves;
-    if (FMT == kFmtUC8)
-        for (uint32_t i = threadIdx.x; i < 16384; i += kT) {  // the scan kernel's folded table (uc8_addr)
-            const uint32_t ai = i & 127, aq = i >> 7;
-            sh.lut[i ^ ((aq & 31) << 1)] = (uint16_t)(a.tab.uc8_lut[((128 + aq) << 8) | (128 + ai)] ^ kBias);
-        }
+    if (FMT == kFmtUC8) fill_radial_table(sh.lut, a.tab.uc8_lut, kBias, threadIdx.x, kT);  // the scan kernel's radial table
     for (uint32_t i = threadIdx.x; i < 160; i += kT) {
         const uint32_t row = i >> 4, e = i & 15;
         sh.coef[row][e] = e < 15 ? coef_entry((int)(row / 5), (int)(row % 5), (int)(e / 3), (int)(e % 3)) : 0u;
@@ -1755,7 +1765,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
                 for (int k = 0; k < 3; ++k) {
                     uint4 o;
                     if constexpr (FMT == kFmtUC8) {
-                        o = uc8_chunk(raw[slot][k][0], sh.lut);
+                        o = uc8_chunk_radial_exact<kBias>(raw[slot][k][0], (uint32_t)(uintptr_t)sh.lut, a.tab.uc8_lut);
                     } else if constexpr (FMT == kFmtMag16) {
                         const uint4 x = raw[slot][k][0];
                         o = make_uint4(x.x ^ kBias2, x.y ^ kBias2, x.z ^ kBias2, x.w ^ kBias2);
@@ -2001,9 +2011,9 @@ constexpr int kAcChunks = (kAcTile + 74 + 7) / 8;        // 8-sample chunks per 
 static_assert(kBlock % kAcTile == 0 && kTrailing % 8 == 6, "tiles start 328 samples into 16-byte aligned IQ");
 
 template <int FMT>
-__device__ __forceinline__ uint4 ac_chunk(const void *iq, int64_t chunk, const uint16_t *lut) {  // 8 samples from iq index 8 * chunk -> 8 magnitudes
+__device__ __forceinline__ uint4 ac_chunk(const void *iq, int64_t chunk, const uint16_t *lut, const uint16_t *full) {  // 8 samples from iq index 8 * chunk -> 8 magnitudes
     if constexpr (FMT == kFmtUC8) {
-        return uc8_chunk(((const uint4 *)iq)[chunk], lut);
+        return uc8_chunk_radial_exact<0u>(((const uint4 *)iq)[chunk], (uint32_t)(uintptr_t)lut, full);
     } else if constexpr (FMT == kFmtMag16) {
         return ((const uint4 *)iq)[chunk];
     } else {
@@ -2031,7 +2041,7 @@ __device__ __forceinline__ unsigned ac_f2_clock(const uint16_t *m, int j, unsign
 }
 
 struct __attribute__((aligned(16))) AcShared {
-    uint16_t lut[16384];
+    uint16_t lut[kRadialEntries];
     uint16_t mt[8 * kAcChunks];
     uint16_t q1[kAcQ1], q2[kAcQ2];
     uint64_t red[2][kAcThreads / 64];
@@ -2104,13 +2114,7 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint64_t blk = blockIdx.x, blk_start = blk * kBlock;
     const uint32_t blk_len = (uint32_t)((a.n - blk_start < (uint64_t)kBlock) ? (a.n - blk_start) : (uint64_t)kBlock);
-    if constexpr (FMT == kFmtUC8) {
-        for (uint32_t i = tid; i < 16384; i += kAcThreads) {
-            const uint32_t ai = i & 127, aq = i >> 7;
-            lut[i ^ ((aq & 31) << 1)] = a.tab.uc8_lut[((128 + aq) << 8) | (128 + ai)];
-        }
-        __syncthreads();
-    }
+    if constexpr (FMT == kFmtUC8) fill_radial_table(lut, a.tab.uc8_lut, 0u, tid, kAcThreads);
 
     // ---- pass 1: sum(mag), sum(mag^2) over the block's new samples iq[blk_start .. blk_start + blk_len)
     if (!a.block_means && !(a.debug_flags & 16)) {
@@ -2124,7 +2128,7 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
         if (a.iq_aligned) {
             const uint32_t nch = blk_len / 8;
             for (uint32_t c = tid; c < nch; c += kAcThreads) {
-                const uint4 o = ac_chunk<FMT>(a.iq, (int64_t)(blk_start / 8 + c), lut);
+                const uint4 o = ac_chunk<FMT>(a.iq, (int64_t)(blk_start / 8 + c), lut, a.tab.uc8_lut);
                 take(o.x & 0xffffu); take(o.x >> 16); take(o.y & 0xffffu); take(o.y >> 16);
                 take(o.z & 0xffffu); take(o.z >> 16); take(o.w & 0xffffu); take(o.w >> 16);
             }
@@ -2168,7 +2172,7 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
     for (uint32_t t0 = 0; t0 < blk_len; t0 += kAcTile) {
         const int64_t q0 = (int64_t)(blk_start + t0) - 2 - (int64_t)kTrailing;  // iq index of mt[0]: a multiple of 8
         if (a.iq_aligned && q0 >= 0 && q0 + 8 * kAcChunks <= (int64_t)a.n) {
-            for (uint32_t c = tid; c < (uint32_t)kAcChunks; c += kAcThreads) ((uint4 *)mt)[c] = ac_chunk<FMT>(a.iq, q0 / 8 + c, lut);
+            for (uint32_t c = tid; c < (uint32_t)kAcChunks; c += kAcThreads) ((uint4 *)mt)[c] = ac_chunk<FMT>(a.iq, q0 / 8 + c, lut, a.tab.uc8_lut);
         } else {  // the batch's first tile (carry), its last ones (end of the stream), unaligned input
             for (uint32_t i = tid; i < 8u * kAcChunks; i += kAcThreads) mt[i] = (uint16_t)stream_mag<FMT>(a, q0 + (int64_t)kTrailing + i);
         }
