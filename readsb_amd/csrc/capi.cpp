@@ -58,6 +58,7 @@ int setup_device(rsb_ctx *c) {
         return rc;
     }
     if ((rc = upload(c, &c->d_lut, uc8_magnitude_lut(), 65536)) != RSB_OK) return rc;
+    if ((rc = upload(c, &c->d_radial, uc8_radial_lut(), (size_t)kRadialEntries)) != RSB_OK) return rc;
     if ((rc = upload(c, &c->d_crc_bytes, CrcTables::byte_table(), 256)) != RSB_OK) return rc;
     if ((rc = upload(c, &c->d_sbs, CrcTables::single_bit_syndromes(), 112)) != RSB_OK) return rc;
     for (int w = 0; w < 2; ++w) {
@@ -454,7 +455,7 @@ void rsb_destroy(rsb_ctx *c) {
     if (c->copy_in_flight && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->h_addr_upload) (void)hipHostFree(c->h_addr_upload);
     if (c->addr_upload_done) (void)hipEventDestroy(c->addr_upload_done);
-    void *ptrs[] = {c->d_lut, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
+    void *ptrs[] = {c->d_lut, c->d_radial, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
                     c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
                     c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge};
     for (rsb_slot &b : c->slots) {

@@ -53,6 +53,7 @@ struct rsb_ctx {
 
     // read-only device tables
     uint16_t *d_lut = nullptr;
+    uint16_t *d_radial = nullptr;
     uint32_t *d_crc_bytes = nullptr;
     uint32_t *d_sbs = nullptr;
     uint32_t *d_syn_keys[2] = {nullptr, nullptr};
@@ -153,6 +154,7 @@ struct rsb_ctx {
         a.fmt = fmt;
         a.n = n;
         a.tab.uc8_lut = d_lut;
+        a.tab.uc8_radial = d_radial;
         a.tab.crc_bytes = d_crc_bytes;
         a.tab.sbs = d_sbs;
         for (int w = 0; w < 2; ++w) {

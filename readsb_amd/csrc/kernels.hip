@@ -441,9 +441,9 @@ static_assert(sizeof(WaveShared) % 16 == 0, "per-wave LDS regions must keep 16-b
 // table of uint16.  (The folded 128 x 128 table needed ~7 instructions per sample for its address.)  Small signals land
 // in a few neighbouring dwords: distinct banks or the same dword, both conflict-free.
 // The reference's float arithmetic breaks the "function of the sum" rule for a few (I, Q): two values of P hold two different
-// magnitudes each (60465/60466 and 49681/49682, 48 of the 65536 byte pairs).  The table build finds such entries by itself
-// and stores magnitude 0 there, which no sample has (the smallest is 363); a strip that reads one is redone on the general path.
-constexpr int kRadialEntries = 16264;  // P / 2 <= 16256, padded to a multiple of 8
+// magnitudes each (60465/60466 and 49681/49682, 48 of the 65536 byte pairs).  The host's table build (modes_host.cpp:
+// uc8_radial_lut) finds such entries by comparing and stores magnitude 0 there, which no sample has (the smallest is 363); a
+// strip that reads one patches those samples from the full table.
 constexpr uint32_t kRadialSentinel = 0u ^ 0x8000u;  // magnitude 0, biased: the smallest int16
 
 struct __attribute__((aligned(16))) ScanShared {
@@ -508,19 +508,17 @@ __device__ __forceinline__ uint4 radial_take(RadialChunk &c, uint32_t &mn) {
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-// The radial table for a whole workgroup (k_scan's prologue in one place): lut[P / 2] = magnitude ^ bias_xor, entries that two
-// byte pairs disagree on = the sentinel (magnitude 0).  Contains workgroup barriers.
-__device__ __forceinline__ void fill_radial_table(uint16_t *lut, const uint16_t *full, uint32_t bias_xor, uint32_t tid, uint32_t nthreads) {
-    for (uint32_t i = tid; i < (uint32_t)kRadialEntries; i += nthreads) lut[i] = (uint16_t)bias_xor;
-    __syncthreads();
-    for (uint32_t i = tid; i < 16384; i += nthreads) {
-        const uint32_t vi = 128 + (i & 127), vq = 128 + (i >> 7);
-        lut[(vi * (255 - vi) + vq * (255 - vq)) >> 1] = (uint16_t)(full[(vq << 8) | vi] ^ bias_xor);
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < 16384; i += nthreads) {
-        const uint32_t vi = 128 + (i & 127), vq = 128 + (i >> 7), k = (vi * (255 - vi) + vq * (255 - vq)) >> 1;
-        if (lut[k] != (uint16_t)(full[(vq << 8) | vi] ^ bias_xor)) lut[k] = (uint16_t)bias_xor;
+// The radial table into a workgroup's LDS: a plain copy of the table the host built (uc8_radial_lut), 16 bytes per load,
+// biased on the way (bias2 = 0x80008000 for kernels that keep magnitudes biased, 0 otherwise).  Ends with a workgroup barrier.
+__device__ __forceinline__ void load_radial_table(uint16_t *lut, const uint16_t *radial, uint32_t bias2, uint32_t tid, uint32_t nthreads) {
+    static_assert(kRadialEntries % 8 == 0, "whole 16-byte pieces");
+    for (uint32_t i = tid; i < (uint32_t)kRadialEntries / 8; i += nthreads) {
+        uint4 v = ((const uint4 *)radial)[i];
+        v.x ^= bias2;
+        v.y ^= bias2;
+        v.z ^= bias2;
+        v.w ^= bias2;
+        ((uint4 *)lut)[i] = v;
     }
     __syncthreads();
 }
@@ -729,7 +727,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     ScanShared &sh = *reinterpret_cast<ScanShared *>(scan_lds);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform: SGPR
 
-    if (FMT == kFmtUC8) fill_radial_table(sh.lut, a.tab.uc8_lut, kBias, tid, kScanThreads);  // (one quadrant of the byte pairs covers every P)
+    if (FMT == kFmtUC8) load_radial_table(sh.lut, a.tab.uc8_radial, kBias2, tid, kScanThreads);
     for (uint32_t i = tid; i < 2 * kBloomWords; i += kScanThreads) sh.bloom[0][i] = 0;
     for (uint32_t i = tid; i < 160; i += kScanThreads) {
         const uint32_t row = i >> 4, e = i & 15;
@@ -1687,7 +1685,14 @@ __global__ __launch_bounds__(kThreads) void k_filter_fill(uint32_t *t0, uint32_t
 // the instruction stream, so no LDS window is needed -- re-slices the winning phase with the scan kernel's per-lane
 // coefficient slicer, repairs it (crc.c:410-418), fills in the fields of mode_s.c:424-562 and the signal level of
 // demod_2400.c:342-354, and writes its 56-byte record.  LDS holds only the tables: 16 wavefronts per CU.
-constexpr int kEmitWaves = 8;   // (16 capped the kernel at 128 VGPRs and made it spill)
+#ifndef RSB_EMIT_WAVES
+#define RSB_EMIT_WAVES 8
+#endif
+#ifndef RSB_EMIT_GROUPS
+#define RSB_EMIT_GROUPS 512
+#endif
+constexpr int kEmitGroups = RSB_EMIT_GROUPS;
+constexpr int kEmitWaves = RSB_EMIT_WAVES;   // per workgroup (16 capped the kernel at 128 VGPRs and made it spill); the grid holds kEmitGroups of them
 constexpr int kEmitTrios = 12;       // 3 chunks = 12 rows (24 samples) = 2 groups of five bits per step; 24 groups >= 23
 
 struct __attribute__((aligned(16))) EmitShared {
@@ -1704,7 +1709,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
     extern __shared__ __attribute__((aligned(16))) unsigned char emit_lds[];  // 66 KB: over the static limit
     EmitShared &sh = *reinterpret_cast<EmitShared *>(emit_lds);
     constexpr uint32_t kT = 64 * kEmitWaves;
-    if (FMT == kFmtUC8) fill_radial_table(sh.lut, a.tab.uc8_lut, kBias, threadIdx.x, kT);  // the scan kernel's radial table
+    if (FMT == kFmtUC8) load_radial_table(sh.lut, a.tab.uc8_radial, kBias2, threadIdx.x, kT);  // the scan kernel's radial table
     for (uint32_t i = threadIdx.x; i < 160; i += kT) {
         const uint32_t row = i >> 4, e = i & 15;
         sh.coef[row][e] = e < 15 ? coef_entry((int)(row / 5), (int)(row % 5), (int)(e / 3), (int)(e % 3)) : 0u;
@@ -2114,7 +2119,7 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint64_t blk = blockIdx.x, blk_start = blk * kBlock;
     const uint32_t blk_len = (uint32_t)((a.n - blk_start < (uint64_t)kBlock) ? (a.n - blk_start) : (uint64_t)kBlock);
-    if constexpr (FMT == kFmtUC8) fill_radial_table(lut, a.tab.uc8_lut, 0u, tid, kAcThreads);
+    if constexpr (FMT == kFmtUC8) load_radial_table(lut, a.tab.uc8_radial, 0u, tid, kAcThreads);
 
     // ---- pass 1: sum(mag), sum(mag^2) over the block's new samples iq[blk_start .. blk_start + blk_len)
     if (!a.block_means && !(a.debug_flags & 16)) {
@@ -2697,7 +2702,7 @@ hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmitShared));
         if (e != hipSuccess) return e;
         const unsigned g = (r.n_items + 64 * kEmitWaves - 1) / (64 * kEmitWaves);
-        hipLaunchKernelGGL(kern, dim3(g < 1 ? 1 : (g > 512 ? 512 : g)), dim3(64 * kEmitWaves), sizeof(EmitShared), s, a, r);
+        hipLaunchKernelGGL(kern, dim3(g < 1 ? 1 : (g > (unsigned)kEmitGroups ? (unsigned)kEmitGroups : g)), dim3(64 * kEmitWaves), sizeof(EmitShared), s, a, r);
         return hipGetLastError();
     });
 }

@@ -24,6 +24,9 @@ constexpr int kScanPasses = RSB_SCAN_PASSES;                 // 512-sample passe
 constexpr int kScanStrip = 512 * kScanPasses - 304;          // ... of which the last 304 are look-ahead only
 constexpr int kScanWavesPerGroup = RSB_SCAN_WAVES;
 
+// UC8 magnitudes by radial index P = I (255 - I) + Q (255 - Q) (even, 0 .. 32512): entry P / 2; padded to a multiple of 8 entries
+constexpr int kRadialEntries = 16264;
+
 // device counters (one uint32 each)
 enum : int {
     kCntItems = 0,     // item records appended by the scan kernel
@@ -52,6 +55,7 @@ enum : int {
 
 struct DeviceTables {      // read-only, built once per context
     const uint16_t *uc8_lut;       // 65536 x u16
+    const uint16_t *uc8_radial;    // kRadialEntries x u16: the same magnitudes by radial index (modes_host.cpp: uc8_radial_lut)
     const uint32_t *crc_bytes;     // 256 x u32
     const uint32_t *sbs;           // 112 x u32: syndrome of each single set bit of a 112-bit frame (crc.c:40)
     const uint32_t *syn_keys[2];   // [0] = 56-bit frames, [1] = 112-bit frames

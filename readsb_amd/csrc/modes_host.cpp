@@ -1,5 +1,6 @@
 // modes_host.cpp -- see modes_host.hpp.  Product code; nothing here comes from oracle/.
 #include "modes_host.hpp"
+#include "kernels.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -325,6 +326,34 @@ int decode_crc_part(const CrcTables &crc, IcaoFilter &filter, rsb_message &m, ui
 }
 
 // =============================================================================== UC8 LUT
+
+const uint16_t *uc8_radial_lut() {
+    // convert.c:35-61 tabulates a function of (2 I - 255)^2 + (2 Q - 255)^2 = 130050 - 4 P, so P / 2 indexes the magnitudes --
+    // except where the reference's float rounding gives byte pairs with one P two different values (magnitudes 60465 / 60466 and
+    // 49681 / 49682): those entries hold 0, a magnitude no sample has (the smallest is 363), and the kernels take such samples from
+    // the full table.  Found here by comparing, not listed by hand.
+    static std::vector<uint16_t> rad;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const uint16_t *full = uc8_magnitude_lut();
+        rad.assign(rsb::kRadialEntries, 0);
+        std::vector<uint8_t> state(rsb::kRadialEntries, 0);  // 0 unset, 1 set, 2 conflicting
+        for (int q = 0; q < 256; ++q)
+            for (int i = 0; i < 256; ++i) {
+                const int k = (i * (255 - i) + q * (255 - q)) >> 1;
+                const uint16_t v = full[(q << 8) | i];
+                if (state[k] == 0) {
+                    rad[k] = v;
+                    state[k] = 1;
+                } else if (state[k] == 1 && rad[k] != v) {
+                    state[k] = 2;
+                }
+            }
+        for (int k = 0; k < rsb::kRadialEntries; ++k)
+            if (state[k] != 1) rad[k] = 0;
+    });
+    return rad.data();
+}
 
 const uint16_t *uc8_magnitude_lut() {
     static std::vector<uint16_t> lut;
