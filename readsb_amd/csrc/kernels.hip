@@ -803,7 +803,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     const uint32_t strip_step = 1;
     const uint64_t first = (uint64_t)gwave * a.strips_per_wave;
     const uint32_t strip_lo = first < nstrips ? (uint32_t)first : nstrips;
-    const uint32_t strip_hi = first + a.strips_per_wave < nstrips ? (uint32_t)(first + a.strips_per_wave) : nstrips;
+    const uint32_t strip_hi = a.stage_limit < 1 ? strip_lo  // (ablation: the table set-up alone)
+                                                : (first + a.strips_per_wave < nstrips ? (uint32_t)(first + a.strips_per_wave) : nstrips);
     if (RSB_PREFETCH_EARLY && strip_lo < strip_hi) prefetch(strip_lo);
     DBG_DECL
     for (uint32_t strip = strip_lo; strip < strip_hi; strip += strip_step) {
@@ -2701,7 +2702,9 @@ hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream
         auto kern = k_replay_emit<decltype(F)::value>;
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmitShared));
         if (e != hipSuccess) return e;
-        const unsigned g = (r.n_items + 64 * kEmitWaves - 1) / (64 * kEmitWaves);
+        // r.n_items bounds the KEPT ITEMS; messages are a third of them or fewer, and every workgroup pays a 32 KB table copy: a
+        // grid for a quarter of the bound (the kernel strides over whatever the count turns out to be)
+        const unsigned g = (r.n_items / 4 + 64 * kEmitWaves - 1) / (64 * kEmitWaves);
         hipLaunchKernelGGL(kern, dim3(g < 1 ? 1 : (g > (unsigned)kEmitGroups ? (unsigned)kEmitGroups : g)), dim3(64 * kEmitWaves), sizeof(EmitShared), s, a, r);
         return hipGetLastError();
     });
