@@ -20,6 +20,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", f"prof_{tag}"), os.path.join(root, "profiles")
 
 scan_avg_ns = None
+for f in glob.glob(os.path.join(src, "trace_default", "**", "*kernel_stats.csv"), recursive=True)[:1]:
+    shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats_default_command.csv"))  # two steps in flight, profiler's blit copy beside the scan
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
@@ -38,7 +40,7 @@ sha = hashlib.sha256()
 for f in ("kernels.hip", "kernels.hpp"):
     sha.update(open(os.path.join(root, "readsb_amd", "csrc", f), "rb").read())
 head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-out = {"kernel": "k_scan<UC8>", "command": "python3 bench.py --warmup 1 --no-cpu-baseline --steps-in-flight 1 --steps 2 (one rocprofv3 --pmc pass per counter group; kernel trace: the default command)",
+out = {"kernel": "k_scan<UC8>", "command": "python3 bench.py --warmup 1 --no-cpu-baseline --steps-in-flight 1 --steps 2 (one rocprofv3 --pmc pass per counter group; kernel trace: the same, --steps 5; the default command's trace is <tag>_kernel_stats_default_command.csv)",
        "git_head_at_summary": head, "kernel_src_sha256": sha.hexdigest(), "samples_per_launch": samples,
        "launches_averaged": {k: len(v) for k, v in cnt.items()}, "per_launch": per}
 d = {}
