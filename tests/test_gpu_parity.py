@@ -590,3 +590,34 @@ def test_prepare_and_fence_order_the_next_scan_on_the_device(built):
         ch.collect_wait()
         assert first_mismatch(want[k].view(REC_DTYPE), out.view(REC_DTYPE)) is None
     ch.close()
+
+
+def test_two_half_collect_error_behaviour(built):
+    """rsb_collect_begin / _prepare / _fence without a submitted batch fail with RSB_ESTATE and a message; rsb_collect_wait without
+    a copy in flight is a no-op; a pageable output buffer works (the call then simply blocks); a short buffer keeps the first
+    cap records and reports the overflow, as rsb_collect does."""
+    sc, kw = SCENARIOS["cfg1_df11_df17"]
+    iq = generate(sc)
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], max_batch_samples=1 << 22)
+    out = np.zeros(1 << 14, dtype=readsb_amd.MSG_DTYPE)  # pageable
+    for call in (lambda: ch.collect_begin(out), ch.collect_prepare, ch.collect_fence):
+        with pytest.raises(readsb_amd.RsbError):
+            call()
+    ch.collect_wait()
+    want = ch.process_host(iq).copy()
+    ch.reset()
+    import torch
+
+    dev = torch.from_numpy(iq).cuda()
+    ch.submit(dev.data_ptr(), iq.shape[0])
+    got = ch.collect_begin(out)
+    ch.collect_wait()
+    assert first_mismatch(want.view(REC_DTYPE), got.view(REC_DTYPE)) is None
+    ch.reset()
+    ch.submit(dev.data_ptr(), iq.shape[0])
+    small = np.zeros(100, dtype=readsb_amd.MSG_DTYPE)
+    with pytest.raises(readsb_amd.RsbError, match="exceed cap"):
+        ch.collect_begin(small)
+    ch.collect_wait()
+    assert first_mismatch(want[:100].view(REC_DTYPE), small.view(REC_DTYPE)) is None
+    ch.close()
