@@ -141,8 +141,8 @@ def launch_ranks(n: int) -> int:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--samples", type=int, default=1 << 30, help="samples per GPU per step")
     ap.add_argument("--segment", type=int, default=1 << 23, help="synthetic segment that is tiled to --samples")
     ap.add_argument("--batches", type=int, default=1, help="submit the recording as this many batches")
