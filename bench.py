@@ -164,7 +164,6 @@ def main() -> int:
     ap.add_argument("--modeac", action="store_true", help="configs[4]: also demodulate2400AC")
     ap.add_argument("--fix-bits", type=int, default=1, choices=(0, 1, 2), help="0 --no-fix, 1 --fix (default), 2 --aggressive (configs[4])")
     ap.add_argument("--dense", action="store_true", help="configs[4] traffic: dense, low SNR, 1- and 2-bit errors, Mode A/C replies")
-    ap.add_argument("--collect-threads", type=int, default=1, help="with --channels-per-gpu: host threads that collect channels side by side")
     ap.add_argument("--channels-per-gpu", type=int, default=1,
                     help="configs[3]: split each GPU's --samples over this many independent receiver channels (own filter, own stream position), "
                          "all submitted before the first is collected")
@@ -226,12 +225,6 @@ def main() -> int:
     base = iq.data_ptr()
     chan_msgs = [0, 0]  # [start, end) of channel 0's records in outbuf after a step
 
-    pool = None
-    if C > 1 and args.collect_threads > 1:
-        from concurrent.futures import ThreadPoolExecutor
-
-        pool = ThreadPoolExecutor(max_workers=args.collect_threads)
-
     def step(tm=None):
         """One pass over the recording: batch i + 1 is submitted before batch i is collected; with several channels every
         channel's scan is submitted before the first channel is collected."""
@@ -267,41 +260,23 @@ def main() -> int:
                 done += 1
             chan_msgs[1] = pos
         else:
-            for i, c in enumerate(chans):
-                c.reset()
-                c.submit(base + bps * nc * i, nc, stream)
+            # configs[3]: N blocks x C channels through the batched entry points (rsb_submit_many / rsb_collect_many: all scans
+            # queued, all replay chains enqueued before the first wait, records leaving while the next channel is looked at)
             for c in chans:
-                c.collect_prepare()  # every channel's prune / replay / emit chain goes onto its own stream: they run side by side
-            if args.collect_threads > 1:
-                # the channels' tails (prune, replay, emit, record copy: a few host waits each) are independent: one host thread
-                # per channel in flight, every channel's records into its own slice of the pinned buffer
-                per = cap // C
-
-                def one(i):
-                    return chans[i].collect(out=outbuf[i * per:(i + 1) * per]).size
-
-                sizes = list(pool.map(one, range(C)))
-                for i in range(1, C):  # close the gaps: one list, channel after channel
-                    outbuf[sum(sizes[:i]):sum(sizes[:i + 1])] = outbuf[i * per:i * per + sizes[i]]
-                pos = sum(sizes)
-                chan_msgs[1] = sizes[0]
-                t = chans[0].timing()
+                c.reset()
+            readsb_amd.submit_many(chans, [base + bps * nc * i for i in range(C)], [nc] * C, stream)
+            per = cap // C
+            views = readsb_amd.collect_many(chans, [outbuf[i * per:(i + 1) * per] for i in range(C)])
+            chan_msgs[1] = views[0].size
+            for c in chans:
+                t = c.timing()
                 for k in keys:
-                    acc[k] = t[k] * (C if k.endswith("_ms") else 1)
-            else:
-                for i, c in enumerate(chans):  # every channel's records leave while the next channel is collected
-                    m = c.collect_begin(outbuf[pos:])
-                    pos += m.size
-                    t = c.timing()
-                    for k in keys:
-                        acc[k] = min(acc[k], t[k]) if k == "replay_on_device" else max(acc[k], t[k]) if k == "replay_iterations" else acc[k] + t[k]
-                    if i == 0:
-                        chan_msgs[1] = pos
-                for c in chans:
-                    c.collect_wait()
+                    acc[k] = min(acc[k], t[k]) if k == "replay_on_device" else max(acc[k], t[k]) if k == "replay_iterations" else acc[k] + t[k]
         if tm is not None:
             for k in keys:
                 tm[k].append(acc[k])
+        if C > 1:
+            return views  # one list per channel, each in its own part of the pinned buffer (joined after the timed region)
         return outbuf[:pos] if args.output == "records" else wirebuf[:pos]
 
     def barrier():
@@ -361,6 +336,8 @@ def main() -> int:
             msgs = step(tm)
     barrier()
     dt = time.perf_counter() - t0
+    if isinstance(msgs, list):
+        msgs = np.concatenate(msgs)
     serial_ms = None
     if overlap:  # for the record, outside the timed region: the same steps one at a time (submit -> collect latency of one recording)
         torch.cuda.synchronize()
@@ -446,7 +423,7 @@ def main() -> int:
                        "batches_per_step": len(cuts) - 1, "batches_in_flight": min(args.in_flight, len(cuts) - 1), "scan_workgroups": scan_wgs or "all",
                        "steps_in_flight": 2 if overlap else 1,
                        **({"ms_per_step_one_at_a_time": serial_ms} if serial_ms is not None else {}),
-                       "channels": world * C, "channels_per_gpu": C, "collect_threads": args.collect_threads if C > 1 else 1, "messages_per_step": nmsgs, "survivors_per_step": st["survivors"],
+                       "channels": world * C, "channels_per_gpu": C, "messages_per_step": nmsgs, "survivors_per_step": st["survivors"],
                        "full_size_check": parity, "oracle_check": oracle_check, "ranks_with_checks_ok": checks_ok, "output": args.output,
                        **({"wire_bytes_per_step": int(wire_bytes.size), "wire_check": wire_check} if wire_check else {})},
             "roofline": {"bound": "hbm", "kernel": f"k_scan<{'Mag16' if args.dcfilter else args.format}>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -208,6 +208,16 @@ int rsb_collect(rsb_ctx *ctx, rsb_message *out, size_t cap, size_t *n_out);
  * results ready.  Optional (rsb_collect does it otherwise) and a no-op for batches that need the host's step-by-step path.
  * Filter changes made between prepare and collect (rsb_filter_add*, rsb_filter_expire) apply from the next batch on. */
 int rsb_collect_prepare(rsb_ctx *ctx);
+/* N blocks x C channels in one call (last row): channel i's batch iq_dev[i][0 .. nsamples[i]) is submitted on
+ * `stream` for every i, and rsb_collect_many fetches every channel's messages into out[i][0 .. cap[i]) (n_out[i] of them).
+ * The channels are independent receivers (own filter, own stream position: ctx[i] from rsb_create), so this is rsb_submit /
+ * rsb_collect per channel with the order that keeps the GPU busy: all scans queued first, all replay chains enqueued before the
+ * first wait (they run side by side on the contexts' own streams), every channel's records crossing PCIe while the next
+ * channel's results are looked at.  out[i] in pinned memory for that last part.  The first error is returned after every channel
+ * has been handled (rsb_last_error on the contexts says which). */
+int rsb_submit_many(rsb_ctx *const *ctx, size_t nch, const void *const *iq_dev, const uint64_t *nsamples, void *stream);
+int rsb_collect_many(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, const size_t *cap, size_t *n_out);
+
 /* Device-side ordering without the host: work enqueued on `stream` after this call starts only when the chain that
  * rsb_collect_prepare put on the context's own stream has finished (without a prepared chain: when the batch's scan has).  For a
  * caller that wants the NEXT scan -- of this or another context; a scan takes every CU and nothing runs beside it -- queued

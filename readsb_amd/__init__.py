@@ -77,6 +77,8 @@ SYMBOLS = {
     "rsb_collect_wait": (C.c_int, [_VP]),
     "rsb_collect_prepare": (C.c_int, [_VP]),
     "rsb_collect_fence": (C.c_int, [_VP, _VP]),
+    "rsb_submit_many": (C.c_int, [_VP, _SZ, _VP, _VP, _VP]),
+    "rsb_collect_many": (C.c_int, [_VP, _SZ, _VP, _VP, _VP]),
     "rsb_process": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_process_host": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_get_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
@@ -129,6 +131,30 @@ class RsbError(RuntimeError):
 
 
 STREAM_SINK = C.CFUNCTYPE(None, _VP, _VP, _SZ)
+
+
+def submit_many(chans, dev_ptrs, nsamples, stream: int = 0):
+    """rsb_submit_many: one batch per channel"""
+    n = len(chans)
+    ctx = (_VP * n)(*[c.h for c in chans])
+    iq = (_VP * n)(*[int(p) for p in dev_ptrs])
+    ns = (C.c_uint64 * n)(*[int(x) for x in nsamples])
+    rc = chans[0].l.rsb_submit_many(ctx, n, iq, ns, stream)
+    if rc != 0:
+        raise RsbError(f"rsb_submit_many: {rc}")
+
+
+def collect_many(chans, outs):
+    """rsb_collect_many: outs[i] = a (pinned) MSG_DTYPE array per channel -> list of views holding each channel's messages"""
+    n = len(chans)
+    ctx = (_VP * n)(*[c.h for c in chans])
+    op = (_VP * n)(*[o.ctypes.data for o in outs])
+    cap = (_SZ * n)(*[o.size for o in outs])
+    cnt = (_SZ * n)()
+    rc = chans[0].l.rsb_collect_many(ctx, n, op, cap, cnt)
+    if rc != 0:
+        raise RsbError(f"rsb_collect_many: {rc}")
+    return [o[:int(k)] for o, k in zip(outs, cnt)]
 
 
 class Stream:

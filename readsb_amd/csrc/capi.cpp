@@ -1126,6 +1126,39 @@ int rsb_collect_begin(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     return rc;
 }
 
+int rsb_submit_many(rsb_ctx *const *ctx, size_t nch, const void *const *iq_dev, const uint64_t *nsamples, void *stream) {
+    if (!ctx || !iq_dev || !nsamples) return RSB_EINVAL;
+    for (size_t i = 0; i < nch; ++i) {
+        if (!ctx[i]) return RSB_EINVAL;
+        const int rc = rsb_submit(ctx[i], iq_dev[i], nsamples[i], stream);
+        if (rc != RSB_OK) return rc;  // (channels before i stay submitted: collect them)
+    }
+    return RSB_OK;
+}
+
+int rsb_collect_many(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, const size_t *cap, size_t *n_out) {
+    if (!ctx || !out || !cap || !n_out) return RSB_EINVAL;
+    for (size_t i = 0; i < nch; ++i)
+        if (!ctx[i] || (!out[i] && cap[i])) return RSB_EINVAL;
+    int first = RSB_OK;
+    // every channel's prune / replay / emit chain onto its own stream first: they run side by side ...
+    for (size_t i = 0; i < nch; ++i) {
+        const int rc = rsb_collect_prepare(ctx[i]);
+        if (rc != RSB_OK && first == RSB_OK) first = rc;
+    }
+    // ... then the host part channel by channel, each channel's records leaving while the next channel is looked at
+    for (size_t i = 0; i < nch; ++i) {
+        n_out[i] = 0;
+        const int rc = rsb_collect_begin(ctx[i], out[i], cap[i], &n_out[i]);
+        if (rc != RSB_OK && first == RSB_OK) first = rc;
+    }
+    for (size_t i = 0; i < nch; ++i) {
+        const int rc = rsb_collect_wait(ctx[i]);
+        if (rc != RSB_OK && first == RSB_OK) first = rc;
+    }
+    return first;
+}
+
 int rsb_collect_wire(rsb_ctx *c, int wire, uint32_t flags, uint8_t *out, size_t cap, size_t *nbytes, size_t *n_msgs) {
     if (!c || (!out && cap) || !nbytes || (wire != RSB_WIRE_BEAST && wire != RSB_WIRE_RAW)) return RSB_EINVAL;
     *nbytes = 0;

@@ -621,3 +621,38 @@ def test_two_half_collect_error_behaviour(built):
     ch.collect_wait()
     assert first_mismatch(want[:100].view(REC_DTYPE), small.view(REC_DTYPE)) is None
     ch.close()
+
+
+def test_many_channels_in_one_call(built):
+    """rsb_submit_many / rsb_collect_many (N blocks x C channels): four independent receivers, two batches each, through
+    the batched entry points = each receiver's own submit / collect, list for list (filters and stream positions stay per channel)."""
+    import torch
+
+    nb = 4 * 131072
+    iqs = [generate(Scenario_for(k)) for k in range(4)]
+    devs = [torch.from_numpy(x).cuda() for x in iqs]
+    want = []
+    for x, d in zip(iqs, devs):
+        ch = readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=nb)
+        parts = []
+        for a in range(0, x.shape[0], nb):
+            ch.submit(d.data_ptr() + 2 * a, min(nb, x.shape[0] - a))
+            parts.append(ch.collect(cap=1 << 14).copy())
+        want.append(parts)
+        ch.close()
+    chans = [readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=nb) for _ in range(4)]
+    outs = [torch.empty((1 << 14) * 56, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE) for _ in range(4)]
+    for b, a in enumerate(range(0, iqs[0].shape[0], nb)):
+        readsb_amd.submit_many(chans, [d.data_ptr() + 2 * a for d in devs], [min(nb, x.shape[0] - a) for x in iqs])
+        got = readsb_amd.collect_many(chans, outs)
+        for k in range(4):
+            assert first_mismatch(want[k][b].view(REC_DTYPE), got[k].view(REC_DTYPE)) is None
+    assert sum(p.size for parts in want for p in parts) > 2000
+    for c in chans:
+        c.close()
+
+
+def Scenario_for(k):
+    from readsb_amd.synth import Scenario
+
+    return Scenario(7 * 131072 + 4000, seed=300 + k, frames_per_sec=3000 + 500 * k)
