@@ -78,6 +78,15 @@ typedef struct rsb_config {
  * first (rsb_superset_add).  For decoding ONE recording in shards on several GPUs; see rsb_seek. */
 #define RSB_FLAG_DEFER_PRUNE 4u
 
+/* SC16Q11 input as a reference BUILT with -DSC16Q11_TABLE_BITS=bits converts it (convert_sc16q11_table, convert.c:264-328, chosen
+ * by convert.c:451-456 in place of convert_sc16q11_nodc): |I| and |Q| masked to 11 bits, the low 11 - bits of each dropped, the
+ * magnitude looked up in a 2^(2 bits)-entry table.  The device computes each entry's formula (convert.c:283-290) instead of
+ * holding the table, so any 1..11 bits cost the same.  Needs input_format RSB_SC16Q11 and no dc_filter (as the reference's
+ * converter list); the block means are the integer ones of convert.c:321-327.  The context holds the batch's magnitudes,
+ * so one batch is in flight at a time and rsb_seek is not available, as with dc_filter.  0 bits = the float converter. */
+#define RSB_FLAG_SC16Q11_TABLE(bits) (((uint32_t)(bits) & 15u) << 8)
+#define RSB_FLAG_SC16Q11_TABLE_BITS_OF(flags) (((uint32_t)(flags) >> 8) & 15u)
+
 /* One decoded message: the fields of struct modesMessage (readsb.h:421-439) that the hot path
  * itself produces.  Packed, 56 bytes. */
 #pragma pack(push, 1)
@@ -236,8 +245,8 @@ int rsb_process(rsb_ctx *ctx, const void *iq_dev, uint64_t nsamples, void *strea
 int rsb_process_host(rsb_ctx *ctx, const void *iq_host, uint64_t nsamples,
                      rsb_message *out, size_t cap, size_t *n_out);
 
-/* --dcfilter contexts only: the magnitudes the converter produced for the last collected batch (what iq_convert_fn
- * would have written, convert.c:113-423) and, if block_means != NULL and the context runs Mode A/C, mean level / mean
+/* --dcfilter and RSB_FLAG_SC16Q11_TABLE contexts only: the magnitudes the converter produced for the last collected batch (what
+ * iq_convert_fn would have written, convert.c:113-423) and, if block_means != NULL and the context runs Mode A/C, mean level / mean
  * power of each of its 131072-sample blocks.  For checking the demodulators apart from the converter's tolerance. */
 int rsb_get_batch_magnitudes(rsb_ctx *ctx, uint16_t *mag_host, uint64_t nsamples, double *block_means);
 

@@ -10,6 +10,7 @@
  *   init_converter            convert.h:41-44, convert.c:446-491   rsbd_init_converter
  *   iq_convert_fn             convert.h:34-39, convert.c:63-423    rsbd_iq_convert_fn (returned)
  *   cleanup_converter         convert.h:46,    convert.c:493-499   rsbd_cleanup_converter
+ *   -DSC16Q11_TABLE_BITS=n    convert.c:264-328, 451-456           rsbd_set_sc16q11_table_bits
  *   modesChecksumInit         crc.h:40,        crc.c:353-378       rsbd_modesChecksumInit
  *   modesChecksum             crc.h:41,        crc.c:67-82         rsbd_modesChecksum
  *   modesChecksumDiagnose     crc.h:42,        crc.c:383-406       rsbd_modesChecksumDiagnose
@@ -59,6 +60,12 @@ typedef void (*rsbd_iq_convert_fn)(void *iq_data, uint16_t *mag_data, unsigned n
  * float32 running sums (convert.c:226-262) are taken in sample order on the device. */
 rsbd_iq_convert_fn rsbd_init_converter(int format, double sample_rate, int filter_dc, struct rsbd_converter_state **out_state);
 void rsbd_cleanup_converter(struct rsbd_converter_state *state);
+
+/* The reference's build option -DSC16Q11_TABLE_BITS=bits (convert.c:264-328, 451-456) as a run-time, process-wide setting: with
+ * bits in 1..11, every rsbd_init_converter(INPUT_SC16Q11, ..., filter_dc = 0) and rsbd_ifileOpen of that format made AFTERWARDS
+ * converts as convert_sc16q11_table does (bit for bit, integer block means), as a shim for a readsb built with that macro must.
+ * 0 (the default) = convert_sc16q11_nodc.  Returns 0, or -1 for a value outside 0..11. */
+int rsbd_set_sc16q11_table_bits(int bits);
 
 /* ---- crc.h (host tables; the kernels carry their own copies) ------------------------------------ */
 

@@ -239,6 +239,8 @@ struct orc_ctx {
     icao_filter filter;
     /* struct converter_state, convert.c:26-31 */
     float dc_a, dc_b, z1_I, z1_Q;
+    int q11_table_bits;          /* 0: the default build; n: the reference built with -DSC16Q11_TABLE_BITS=n (convert.c:264-328) */
+    uint16_t *q11_lookup;
     orc_stats stats;
     /* message sink */
     orc_msg *out;
@@ -320,6 +322,7 @@ void orc_destroy(orc_ctx *c) {
         return;
     free(c->tab_short);
     free(c->tab_long);
+    free(c->q11_lookup);
     free(c);
 }
 
@@ -354,7 +357,28 @@ static void checksum_fix(uint8_t *msg, const orc_errorinfo *info) {
 
 /* ------------------------------------------------------------------ converters (convert.c) */
 
-/* one routine per table row of convert.c:431-444 (default build: SC16Q11_TABLE_BITS undefined) */
+/* convert.c:264-295 with SC16Q11_TABLE_BITS = bits: the build of the reference that some packages ship (armhf: 8) */
+void orc_set_sc16q11_table_bits(orc_ctx *c, int bits) {
+    free(c->q11_lookup);
+    c->q11_lookup = NULL;
+    c->q11_table_bits = (bits >= 1 && bits <= 11) ? bits : 0;
+    if (!c->q11_table_bits)
+        return;
+    const int use_bits = c->q11_table_bits, lose_bits = 11 - use_bits;
+    c->q11_lookup = malloc(sizeof (uint16_t) * ((size_t) 1 << (use_bits * 2)));
+    for (int i = 0; i < 2048; i += (1 << lose_bits))
+        for (int q = 0; q < 2048; q += (1 << lose_bits)) {
+            float fI = i / 2048.0, fQ = q / 2048.0;
+            float magsq = fI * fI + fQ * fQ;
+            if (magsq > 1)
+                magsq = 1;
+            float mag = sqrtf(magsq);
+            unsigned index = ((i >> lose_bits) << use_bits) | (q >> lose_bits);
+            c->q11_lookup[index] = (uint16_t) (mag * 65535.0f + 0.5f);
+        }
+}
+
+/* one routine per table row of convert.c:431-444 */
 void orc_convert(orc_ctx *c, const void *iq, uint16_t *mag_data, unsigned nsamples, double *out_mean_level, double *out_mean_power) {
     if (c->format == ORC_UC8 && !c->dc_filter) {
         /* convert_uc8_nodc, convert.c:63-111: the 16-bit little-endian word (I | Q<<8) indexes the LUT */
@@ -362,6 +386,26 @@ void orc_convert(orc_ctx *c, const void *iq, uint16_t *mag_data, unsigned nsampl
         uint64_t sum_level = 0, sum_power = 0;
         for (unsigned i = 0; i < nsamples; ++i) {
             uint16_t mag = uc8_lookup[in[i]];
+            mag_data[i] = mag;
+            sum_level += mag;
+            sum_power += (uint32_t) mag * (uint32_t) mag;
+        }
+        if (out_mean_level)
+            *out_mean_level = sum_level / 65536.0 / nsamples;
+        if (out_mean_power)
+            *out_mean_power = sum_power / 65535.0 / 65535.0 / nsamples;
+        return;
+    }
+
+    if (c->format == ORC_SC16Q11 && !c->dc_filter && c->q11_table_bits) {
+        /* convert_sc16q11_table, convert.c:297-328 */
+        const int use_bits = c->q11_table_bits, lose_bits = 11 - use_bits;
+        const int16_t *in = iq;
+        uint64_t sum_level = 0, sum_power = 0;
+        for (unsigned i = 0; i < nsamples; ++i) {
+            uint16_t I = abs((int16_t) in[2 * i]) & 2047;
+            uint16_t Q = abs((int16_t) in[2 * i + 1]) & 2047;
+            uint16_t mag = c->q11_lookup[((I >> lose_bits) << use_bits) | (Q >> lose_bits)];
             mag_data[i] = mag;
             sum_level += mag;
             sum_power += (uint32_t) mag * (uint32_t) mag;

@@ -59,6 +59,7 @@ typedef struct orc_ctx orc_ctx;
 
 orc_ctx *orc_create(int format, int dc_filter, int nfix, int modeac);
 void orc_destroy(orc_ctx *c);
+void orc_set_sc16q11_table_bits(orc_ctx *c, int bits); /* 0 = the default build of the reference */
 void orc_reset(orc_ctx *c); /* filter, converter state, stats, stream position */
 
 /* whole-stream run in the sdr_ifile.c block model; returns number of messages (may exceed cap;

@@ -84,11 +84,14 @@ def iq_bytes(iq: np.ndarray) -> np.ndarray:
 
 
 class Oracle:
-    def __init__(self, fmt="UC8", dc_filter=False, nfix=1, modeac=False):
+    def __init__(self, fmt="UC8", dc_filter=False, nfix=1, modeac=False, q11_table_bits=0):
         self.lib = _lib()
         self.fmt = fmt
         self.bps = 2 if fmt == "UC8" else 4
         self.h = self.lib.orc_create(FORMATS[fmt], int(dc_filter), int(nfix), int(modeac))
+        if q11_table_bits:  # the reference built with -DSC16Q11_TABLE_BITS=n (convert.c:264-328)
+            self.lib.orc_set_sc16q11_table_bits.argtypes = [C.c_void_p, C.c_int]
+            self.lib.orc_set_sc16q11_table_bits(self.h, int(q11_table_bits))
         if not self.h:
             raise ValueError("no suitable converter")
 
@@ -190,6 +193,7 @@ def forward_order(recs: np.ndarray) -> np.ndarray:
 
 
 REF_GPU_BIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "ref_harness_gpu")
+REF_T8_BIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "ref_harness_t8")  # reference built with -DSC16Q11_TABLE_BITS=8
 
 
 class RefHarness:
@@ -232,11 +236,11 @@ class RefHarness:
         return st
 
     @staticmethod
-    def convert(iq: np.ndarray, fmt="UC8", dc_filter=False, chunk=131072):
+    def convert(iq: np.ndarray, fmt="UC8", dc_filter=False, chunk=131072, binary=None):
         with tempfile.TemporaryDirectory() as d:
             fin, fout = os.path.join(d, "in.iq"), os.path.join(d, "out.bin")
             iq_bytes(iq).tofile(fin)
-            subprocess.run([REF_BIN, "convert", fmt, str(int(dc_filter)), str(chunk), fin, fout], check=True)
+            subprocess.run([binary or REF_BIN, "convert", fmt, str(int(dc_filter)), str(chunk), fin, fout], check=True)
             raw = np.fromfile(fout, dtype=np.uint8)
         total, ncalls = (int(x) for x in raw[:16].view("<u8"))
         mag = raw[16:16 + 2 * total].view("<u2").copy()

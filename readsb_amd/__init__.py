@@ -199,12 +199,14 @@ class Channel:
     """One receiver channel (rsb_ctx)."""
 
     def __init__(self, fmt="UC8", fix_bits=1, mode_ac=False, dc_filter=False, device=0, max_batch_samples=1 << 24, queue_div=0,
-                 host_replay=False, exact_stats=False, defer_prune=False, scan_workgroups=0):
+                 host_replay=False, exact_stats=False, defer_prune=False, scan_workgroups=0, q11_table_bits=0):
         self.l = lib()
         self.fmt = fmt
         self.bps = 2 if fmt == "UC8" else 4
         cfg = Config(FORMATS[fmt], int(dc_filter), int(fix_bits), int(mode_ac), int(device), int(queue_div), int(max_batch_samples),
-                     (FLAG_HOST_REPLAY if host_replay else 0) | (FLAG_EXACT_STATS if exact_stats else 0) | (FLAG_DEFER_PRUNE if defer_prune else 0), int(scan_workgroups))
+                     (FLAG_HOST_REPLAY if host_replay else 0) | (FLAG_EXACT_STATS if exact_stats else 0) | (FLAG_DEFER_PRUNE if defer_prune else 0)
+                     | ((int(q11_table_bits) & 15) << 8),  # RSB_FLAG_SC16Q11_TABLE(bits): a reference built with -DSC16Q11_TABLE_BITS
+                     int(scan_workgroups))
         h = _VP()
         rc = self.l.rsb_create(C.byref(cfg), C.byref(h))
         if rc != 0:

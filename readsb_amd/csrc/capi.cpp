@@ -91,8 +91,9 @@ int setup_device(rsb_ctx *c) {
     if (const char *e = std::getenv("RSB_SCAN_GRID")) c->scan_grid = std::atoi(e);
     if (c->cfg.scan_workgroups && (int)c->cfg.scan_workgroups < c->scan_grid) c->scan_grid = (int)c->cfg.scan_workgroups;
     if (c->scan_grid < 1) c->scan_grid = 1;
-    // --dcfilter keeps one magnitude buffer, which the replay of a batch still reads: one batch in flight there
-    c->nslots = c->cfg.dc_filter ? 1 : rsb_ctx::kMaxSlots;
+    // --dcfilter (and the SC16Q11 table converter) keeps one magnitude buffer, which the replay of a batch still reads: one batch in flight there
+    c->q11_table_bits = (int)RSB_FLAG_SC16Q11_TABLE_BITS_OF(c->cfg.flags);
+    c->nslots = (c->cfg.dc_filter || c->q11_table_bits) ? 1 : rsb_ctx::kMaxSlots;
     for (int k = 0; k < c->nslots; ++k) {
         rsb_slot &b = c->slots[k];
         HIP_TRY(c, hipMalloc((void **)&b.d_items, (size_t)c->item_cap * sizeof(ItemRec)));
@@ -120,8 +121,8 @@ int setup_device(rsb_ctx *c) {
     HIP_TRY(c, hipMalloc((void **)&c->d_bitmap, (1u << 24) / 8));
     HIP_TRY(c, hipMalloc((void **)&c->d_dc_state, sizeof(double2)));
     HIP_TRY(c, hipMemset(c->d_dc_state, 0, sizeof(double2)));
+    if (c->cfg.dc_filter || c->q11_table_bits) HIP_TRY(c, hipMalloc((void **)&c->d_magbuf, (size_t)nmax * sizeof(uint16_t) + 16));
     if (c->cfg.dc_filter) {
-        HIP_TRY(c, hipMalloc((void **)&c->d_magbuf, (size_t)nmax * sizeof(uint16_t) + 16));
         c->dc_tiles_cap = (size_t)((nmax + kDcTileSamples - 1) / kDcTileSamples) + 1;
         HIP_TRY(c, hipMalloc((void **)&c->d_dc_tile_sums, c->dc_tiles_cap * sizeof(double2)));
         HIP_TRY(c, hipMalloc((void **)&c->d_dc_tile_start, c->dc_tiles_cap * sizeof(double2)));
@@ -436,6 +437,13 @@ int rsb_create(const rsb_config *cfg, rsb_ctx **out) {
         return RSB_EINVAL;
     }
     if (cfg->fix_bits < 0 || cfg->max_batch_samples == 0 || cfg->max_batch_samples > 0xfffff000ull) return RSB_EINVAL;
+    if (const unsigned tb = RSB_FLAG_SC16Q11_TABLE_BITS_OF(cfg->flags)) {
+        // convert.c:451-456: the table converter stands in the converter list for SC16Q11 without the DC filter only
+        if (tb > 11 || cfg->input_format != RSB_SC16Q11 || cfg->dc_filter) {
+            std::fprintf(stderr, "readsb_amd: RSB_FLAG_SC16Q11_TABLE(%u) needs input_format RSB_SC16Q11, no dc_filter and 1..11 bits\n", tb);
+            return RSB_EINVAL;
+        }
+    }
     rsb_ctx *c = new (std::nothrow) rsb_ctx(*cfg);
     if (!c) return RSB_ENOMEM;
     int rc = setup_device(c);
@@ -550,8 +558,9 @@ static int fetch_bitmap(rsb_ctx *c, std::vector<uint32_t> &words) {
 
 int rsb_seek(rsb_ctx *c, uint64_t stream_pos, const void *carry, int carry_on_device) {
     if (!c || c->block_mode) return RSB_EINVAL;
-    if (c->cfg.dc_filter) {
-        c->err = "rsb_seek: not available with dc_filter (the converter's state does not travel)";
+    if (c->cfg.dc_filter || c->q11_table_bits) {
+        c->err = c->cfg.dc_filter ? "rsb_seek: not available with dc_filter (the converter's state does not travel)"
+                                  : "rsb_seek: not available with RSB_FLAG_SC16Q11_TABLE (the carry is kept as magnitudes of the batch before)";
         return RSB_EINVAL;
     }
     if (c->any_pending()) {
@@ -631,7 +640,7 @@ static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t n
         // noise power statistic (:378-382)
         const size_t nblk = (nsamples + kBlock - 1) / kBlock;
         BatchArgs ac = a;
-        if (!ac.block_means && a.fmt != kFmtUC8) {
+        if (!ac.block_means && (a.fmt == kFmtSC16 || a.fmt == kFmtSC16Q11)) {
             // the float converters' block means (convert.c:226-262): exact only in sample order
             HIP_TRY(c, launch_block_means_float(a.fmt, a.iq, nsamples, kBlock, b.d_block_means, s));
             ac.block_means = b.d_block_means;
@@ -691,6 +700,12 @@ int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) 
         BatchArgs a = c->batch_args(b, c->d_magbuf, nsamples, kFmtMag16);
         if (want_means) a.block_means = b.d_block_means;
         return enqueue_batch(c, b, a, nsamples, s);
+    }
+    if (c->q11_table_bits) {
+        // a reference built with -DSC16Q11_TABLE_BITS: magnitudes from the table converter, the block means from their integer
+        // sums (convert.c:321-327, the same expressions as the UC8 converter's, which is what the magnitude path computes)
+        HIP_TRY(c, launch_convert_q11t(iq_dev, c->d_magbuf, nsamples, c->q11_table_bits, nullptr, s));
+        return enqueue_batch(c, b, c->batch_args(b, c->d_magbuf, nsamples, kFmtMag16), nsamples, s);
     }
     return enqueue_batch(c, b, c->batch_args(b, iq_dev, nsamples, c->cfg.input_format), nsamples, s);
 }
@@ -1193,15 +1208,25 @@ int rsb_process_host(rsb_ctx *c, const void *iq_host, uint64_t nsamples, rsb_mes
 
 int rsb_get_batch_magnitudes(rsb_ctx *c, uint16_t *mag_host, uint64_t nsamples, double *block_means) {
     if (!c || !mag_host) return RSB_EINVAL;
-    if (!c->cfg.dc_filter || c->any_pending() || nsamples > c->last_n) {
-        c->err = "rsb_get_batch_magnitudes: only after rsb_collect on a --dcfilter context, at most the batch's samples";
+    if (!c->d_magbuf || c->any_pending() || nsamples > c->last_n) {
+        c->err = "rsb_get_batch_magnitudes: only after rsb_collect on a --dcfilter or RSB_FLAG_SC16Q11_TABLE context, at most the batch's samples";
         return RSB_ESTATE;
     }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipMemcpy(mag_host, c->d_magbuf, (size_t)nsamples * sizeof(uint16_t), hipMemcpyDeviceToHost));
     if (block_means && c->run_ac) {
         const size_t nblk = (size_t)((c->last_n + kBlock - 1) / kBlock);
-        HIP_TRY(c, hipMemcpy(block_means, c->slots[0].d_block_means, nblk * 2 * sizeof(double), hipMemcpyDeviceToHost));
+        if (c->cfg.dc_filter) {
+            HIP_TRY(c, hipMemcpy(block_means, c->slots[0].d_block_means, nblk * 2 * sizeof(double), hipMemcpyDeviceToHost));
+        } else {  // the table converter: from the blocks' integer sums (convert.c:321-327)
+            std::vector<uint64_t> sums(2 * nblk);
+            HIP_TRY(c, hipMemcpy(sums.data(), c->slots[0].d_block_sums, sums.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < nblk; ++k) {
+                const uint64_t len = std::min<uint64_t>(kBlock, c->last_n - k * kBlock);
+                block_means[2 * k] = (double)sums[2 * k] / 65536.0 / (double)(unsigned)len;
+                block_means[2 * k + 1] = (double)sums[2 * k + 1] / 65535.0 / 65535.0 / (double)(unsigned)len;
+            }
+        }
     }
     return RSB_OK;
 }
@@ -1250,10 +1275,13 @@ int rsb_convert_device(rsb_ctx *c, const void *iq_dev, void *mag_dev, uint64_t n
         }
         return RSB_OK;
     }
-    const bool float_path = c->cfg.input_format != RSB_UC8;
+    const bool float_path = c->cfg.input_format != RSB_UC8 && !c->q11_table_bits;
     if (want && !c->d_sums) HIP_TRY(c, hipMalloc((void **)&c->d_sums, 2 * sizeof(uint64_t)));
     if (want && !float_path) HIP_TRY(c, hipMemsetAsync(c->d_sums, 0, 2 * sizeof(uint64_t), s));
-    HIP_TRY(c, launch_convert(c->cfg.input_format, iq_dev, (uint16_t *)mag_dev, nsamples, c->d_lut, (want && !float_path) ? c->d_sums : nullptr, s));
+    if (c->q11_table_bits)  // convert.c:297-328
+        HIP_TRY(c, launch_convert_q11t(iq_dev, (uint16_t *)mag_dev, nsamples, c->q11_table_bits, want ? c->d_sums : nullptr, s));
+    else
+        HIP_TRY(c, launch_convert(c->cfg.input_format, iq_dev, (uint16_t *)mag_dev, nsamples, c->d_lut, (want && !float_path) ? c->d_sums : nullptr, s));
     if (want && float_path) HIP_TRY(c, launch_block_means_float(c->cfg.input_format, iq_dev, nsamples, nsamples, (double *)c->d_sums, s));
     if (want) {
         uint64_t sums[2];
@@ -1264,7 +1292,7 @@ int rsb_convert_device(rsb_ctx *c, const void *iq_dev, void *mag_dev, uint64_t n
             std::memcpy(means, sums, sizeof(means));
             if (mean_level) *mean_level = means[0];
             if (mean_power) *mean_power = means[1];
-        } else {  // convert.c:104-110
+        } else {  // convert.c:104-110 / :321-327
             if (mean_level) *mean_level = sums[0] / 65536.0 / (unsigned)nsamples;
             if (mean_power) *mean_power = sums[1] / 65535.0 / 65535.0 / (unsigned)nsamples;
         }

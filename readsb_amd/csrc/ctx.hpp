@@ -105,6 +105,7 @@ struct rsb_ctx {
     uint64_t *d_sums = nullptr;
     // --dcfilter: magnitudes of the batch (the scan then reads them instead of IQ), the scan's tile arrays, the carried state
     uint16_t *d_magbuf = nullptr;
+    int q11_table_bits = 0;  // RSB_FLAG_SC16Q11_TABLE: the converter of a reference built with -DSC16Q11_TABLE_BITS (0 = the float one)
     double2 *d_dc_tile_sums = nullptr, *d_dc_tile_start = nullptr, *d_dc_state = nullptr;
     size_t dc_tiles_cap = 0;
 

@@ -43,6 +43,14 @@ struct rsbd_converter_state {
 
 namespace {
 
+// what -DSC16Q11_TABLE_BITS=n is to the reference's convert.c (a build option, so process-wide here): 0 = the float converter
+int g_sc16q11_table_bits = 0;
+
+uint32_t table_flag(int format, int filter_dc) {
+    // convert.c:451-456: the table converter takes the place of convert_sc16q11_nodc only
+    return (format == RSB_SC16Q11 && !filter_dc) ? RSB_FLAG_SC16Q11_TABLE(g_sc16q11_table_bits) : 0u;
+}
+
 void convert_entry(void *iq_data, uint16_t *mag_data, unsigned nsamples, rsbd_converter_state *st, double *out_mean_level, double *out_mean_power) {
     // convert.c:63-423: nsamples IQ pairs in, nsamples magnitudes out, optional block means
     if (!st || !iq_data || !mag_data || nsamples == 0) {
@@ -97,7 +105,7 @@ extern "C" rsbd_iq_convert_fn rsbd_init_converter(int format, double sample_rate
     cfg.dc_filter = filter_dc ? 1 : 0;
     cfg.fix_bits = 0;
     cfg.max_batch_samples = filter_dc ? (2u << 20) : 4096;  // the context is used for its tables (and the DC filter's scan arrays) only
-    cfg.flags = RSB_FLAG_HOST_REPLAY;
+    cfg.flags = RSB_FLAG_HOST_REPLAY | table_flag(format, filter_dc);
     rsb_ctx *ctx = nullptr;
     if (rsb_create(&cfg, &ctx) != RSB_OK) return nullptr;  // message already printed
     rsbd_converter_state *st = new (std::nothrow) rsbd_converter_state;
@@ -110,6 +118,12 @@ extern "C" rsbd_iq_convert_fn rsbd_init_converter(int format, double sample_rate
     st->ctx = ctx;
     *out_state = st;
     return convert_entry;
+}
+
+extern "C" int rsbd_set_sc16q11_table_bits(int bits) {
+    if (bits < 0 || bits > 11) return -1;
+    g_sc16q11_table_bits = bits;
+    return 0;
 }
 
 extern "C" void rsbd_cleanup_converter(rsbd_converter_state *st) {
@@ -302,6 +316,7 @@ extern "C" rsbd_ifile *rsbd_ifileOpen(const char *filename, int input_format, in
     cfg.mode_ac = mode_ac ? 1 : 0;
     cfg.device = device;
     cfg.max_batch_samples = f->batch_samples;
+    cfg.flags = table_flag(input_format, filter_dc);
     if (rsb_create(&cfg, &f->ctx) != RSB_OK) {  // unknown format: "no suitable converter ..." (sdr_ifile.c:149-153)
         rsbd_ifileClose(f);
         return nullptr;

@@ -2318,6 +2318,35 @@ __global__ __launch_bounds__(kThreads) void k_convert(const void *iq, uint16_t *
     }
 }
 
+// convert_sc16q11_table (convert.c:297-328), the SC16Q11 converter of a reference built with -DSC16Q11_TABLE_BITS=use_bits:
+// |I|, |Q| masked to 11 bits, their low 11 - use_bits bits dropped, magnitude from a table whose entries are the float32
+// formula of convert.c:281-291 at the kept bits -- computed here directly (float_mag is that formula, op for op; i / 2048.0
+// is exact), so no table has to live anywhere.  Exact integer sums when asked, as launch_convert.
+__global__ __launch_bounds__(kThreads) void k_convert_q11t(const void *iq, uint16_t *mag, uint64_t n, int lose_bits, uint64_t *sums) {
+    uint64_t sl = 0, sp = 0;
+    const uint32_t *in = (const uint32_t *)iq;  // one sample = I | Q << 16
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) {
+        const uint32_t w = in[i];
+        int I = (int)(short)(w & 0xffffu), Q = (int)(short)(w >> 16);
+        I = ((I < 0 ? -I : I) & 2047) >> lose_bits << lose_bits;  // abs((int16_t) x) & 2047: -32768 and +-2048 give 0 (convert.c:313-314)
+        Q = ((Q < 0 ? -Q : Q) & 2047) >> lose_bits << lose_bits;
+        const uint32_t v = float_mag((float)I * (1.0f / 2048.0f), (float)Q * (1.0f / 2048.0f));
+        mag[i] = (uint16_t)v;
+        sl += v;
+        sp += (uint64_t)v * v;
+    }
+    if (sums) {
+        for (int off = 32; off > 0; off >>= 1) {
+            sl += __shfl_down(sl, off, 64);
+            sp += __shfl_down(sp, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd((unsigned long long *)&sums[0], (unsigned long long)sl);
+            atomicAdd((unsigned long long *)&sums[1], (unsigned long long)sp);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // --dcfilter: the generic converters of convert.c:113-162 / :164-213 / :374-423.  The DC block is a first-order
 // recurrence z[n] = x[n] * dc_a + z[n-1] * dc_b per component with the state carried across calls (:152-153), which the
@@ -2881,6 +2910,14 @@ hipError_t launch_convert(int fmt, const void *iq, uint16_t *mag, uint64_t n, co
         hipLaunchKernelGGL(k_convert<decltype(F)::value>, dim3((unsigned)blocks), dim3(kThreads), 0, s, iq, mag, n, lut, sums);
         return hipGetLastError();
     });
+}
+
+hipError_t launch_convert_q11t(const void *iq, uint16_t *mag, uint64_t n, int use_bits, uint64_t *sums, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_convert_q11t, dim3((unsigned)blocks), dim3(kThreads), 0, s, iq, mag, n, 11 - use_bits, sums);
+    return hipGetLastError();
 }
 
 }  // namespace rsb

@@ -195,5 +195,7 @@ constexpr int kDcTileSamples = 4096;
 hipError_t launch_convert_dc(int fmt, const void *iq, uint16_t *mag, uint64_t n, double2 *tile_sums, double2 *tile_start, double2 *z_state, double *block_means,
                              hipStream_t s);
 hipError_t launch_convert(int fmt, const void *iq, uint16_t *mag, uint64_t n, const uint16_t *lut, uint64_t *sums, hipStream_t s);
+// SC16Q11 as a reference built with -DSC16Q11_TABLE_BITS=use_bits converts it (convert.c:297-328); sums as launch_convert's
+hipError_t launch_convert_q11t(const void *iq, uint16_t *mag, uint64_t n, int use_bits, uint64_t *sums, hipStream_t s);
 
 }  // namespace rsb

@@ -24,6 +24,7 @@ class MagBuf(C.Structure):  # struct mag_buf, readsb.h:298-311
 SYMBOLS = {
     "rsbd_init_converter": (_VP, [C.c_int, C.c_double, C.c_int, C.POINTER(_VP)]),
     "rsbd_cleanup_converter": (None, [_VP]),
+    "rsbd_set_sc16q11_table_bits": (C.c_int, [C.c_int]),
     "rsbd_modesChecksumInit": (None, [C.c_int]),
     "rsbd_modesChecksum": (C.c_uint32, [_VP, C.c_int]),
     "rsbd_modesChecksumDiagnose": (C.POINTER(ErrorInfo), [C.c_uint32, C.c_int]),

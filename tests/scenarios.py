@@ -39,6 +39,15 @@ SCENARIOS.update({
     "sc16_ac": (Scenario(600_000, seed=13, fmt="SC16", modeac_per_sec=300), dict(nfix=1, modeac=True)),
 })
 
+# the reference built with -DSC16Q11_TABLE_BITS=8 (convert.c:264-328; what some armhf packages ship).  Golden
+# lists from oracle/_ref/ref_harness_t8 (the same harness over convert.c compiled with the macro).  Kept apart from SCENARIOS:
+# every consumer passes q11_table_bits explicitly.
+TABLE_SCENARIOS = {
+    "sc16q11_table8_ac": (Scenario(900_000, seed=11, fmt="SC16Q11", modeac_per_sec=300), dict(nfix=1, modeac=True, q11_table_bits=8)),
+    "sc16q11_table8_fix2": (Scenario(700_000, seed=12, fmt="SC16Q11", err2_every=9), dict(nfix=2, modeac=False, q11_table_bits=8)),
+}
+TABLE_CONVERT_CASES = {"sc16q11_table8": ("SC16Q11", False, 100_000, 30_000, 8)}
+
 # scenarios the GPU path reproduces bit for bit
 GPU_SCENARIOS = [k for k, (sc, kw) in SCENARIOS.items() if not kw.get("dc_filter")]  # bit-exact ones; --dcfilter has its own test
 

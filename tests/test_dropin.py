@@ -11,7 +11,7 @@ from readsb_amd import dropin
 from oracle.oracle import Oracle, REC_DTYPE, first_mismatch
 from readsb_amd.synth import generate
 
-from scenarios import CONVERT_CASES, SCENARIOS, convert_input
+from scenarios import CONVERT_CASES, SCENARIOS, TABLE_CONVERT_CASES, TABLE_SCENARIOS, convert_input
 from test_oracle import GOLD
 
 B, T = readsb_amd.BLOCK, readsb_amd.TRAILING
@@ -77,6 +77,50 @@ def test_converter_matches_oracle(case, built):
         assert np.array_equal(mag, wmag)
         assert (lvl, pwr) == (wlvl, wpwr)  # SC16: float32 running sums taken in sample order on the device
     conv.close()
+
+
+@pytest.mark.gpu
+def test_table_converter_build_option(built, tmp_path):
+    """rsbd_set_sc16q11_table_bits(8) = -DSC16Q11_TABLE_BITS=8 (convert.c:264-328): init_converter(INPUT_SC16Q11, dc = 0) then hands
+    out convert_sc16q11_table -- magnitudes and integer means bit for bit against the oracle and against the golden output of the
+    reference's convert.c compiled with the macro; the other converters are untouched; the ifile driver follows the setting."""
+    import hashlib
+
+    l = dropin.dlib()
+    assert l.rsbd_set_sc16q11_table_bits(12) == -1 and l.rsbd_set_sc16q11_table_bits(-1) == -1
+    for case, (fmt, dc, n, chunk, bits) in TABLE_CONVERT_CASES.items():
+        assert l.rsbd_set_sc16q11_table_bits(bits) == 0
+        try:
+            iq = convert_input(fmt, n)
+            conv = dropin.Converter(readsb_amd.FORMATS[fmt])
+            orc = Oracle(fmt=fmt, q11_table_bits=bits)
+            mags, means = [], []
+            for lo in range(0, n, chunk):
+                mag, lvl, pwr = conv(iq[lo:lo + chunk])
+                wmag, wlvl, wpwr = orc.convert(iq[lo:lo + chunk])
+                assert np.array_equal(mag, wmag) and (lvl, pwr) == (wlvl, wpwr)
+                mags.append(mag)
+                means.append((lvl, pwr))
+            conv.close()
+            z = np.load(os.path.join(GOLD, f"convert_{case}.npz"))
+            assert hashlib.sha256(np.concatenate(mags).tobytes()).digest() == bytes(z["mag_sha256"])
+            assert np.array_equal(np.array(means), z["means"])
+            # SC16 keeps its float converter under the same setting (convert.c:451-456 lists the table for SC16Q11 only)
+            sc16 = convert_input("SC16", 4096)
+            conv = dropin.Converter(readsb_amd.FORMATS["SC16"])
+            assert np.array_equal(conv(sc16)[0], Oracle(fmt="SC16").convert(sc16)[0])
+            conv.close()
+            name = "sc16q11_table8_ac"
+            sc, kw = TABLE_SCENARIOS[name]
+            rec = generate(sc)
+            path = tmp_path / "rec.iq"
+            np.ascontiguousarray(rec).view(np.uint8).reshape(-1).tofile(path)
+            want, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"], q11_table_bits=bits).run_stream(rec)
+            nread, got = dropin.run_ifile(str(path), readsb_amd.FORMATS[sc.fmt], False, kw["nfix"], kw["modeac"], 0, 3)
+            assert nread == sc.n_samples
+            assert first_mismatch(want, got.view(REC_DTYPE)) is None
+        finally:
+            assert l.rsbd_set_sc16q11_table_bits(0) == 0
 
 
 @pytest.mark.gpu

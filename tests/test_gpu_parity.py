@@ -6,7 +6,7 @@ import readsb_amd
 from oracle.oracle import Oracle, REC_DTYPE, first_mismatch
 from readsb_amd.synth import generate
 
-from scenarios import GPU_SCENARIOS, SCENARIOS
+from scenarios import GPU_SCENARIOS, SCENARIOS, TABLE_SCENARIOS
 from test_oracle import load_demod
 
 pytestmark = pytest.mark.gpu
@@ -88,6 +88,45 @@ def test_dcfilter_stream(name, built):
         for f in ("msgtype", "crc", "correctedbits", "addr", "score", "source", "iid"):
             assert a[f] == b[f], (k, f)
         assert abs(a["signal"] - b["signal"]) <= rel * abs(a["signal"]) + 1e-12
+
+
+@REPLAY
+@pytest.mark.parametrize("batch_blocks", [0, 2])
+@pytest.mark.parametrize("name", list(TABLE_SCENARIOS))
+def test_sc16q11_table_build_stream(name, batch_blocks, host_replay, built):
+    """RSB_FLAG_SC16Q11_TABLE(8) = a reference built with -DSC16Q11_TABLE_BITS=8 (convert.c:264-328).  Bit for bit
+    against the oracle set up the same way and against the golden list of oracle/_ref/ref_harness_t8 (the reference's convert.c
+    compiled with the macro), in one shot and in two-block batches (the overlap then comes from the previous batch's magnitudes)."""
+    sc, kw = TABLE_SCENARIOS[name]
+    bits = kw["q11_table_bits"]
+    iq = generate(sc)
+    orc = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"], q11_table_bits=bits)
+    want, wst = orc.run_stream(iq)
+    gold, _, _ = load_demod(name)
+    assert first_mismatch(gold, want) is None
+    plain, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
+    assert first_mismatch(plain, want) is not None  # the scenario tells the two builds apart
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], q11_table_bits=bits, host_replay=host_replay,
+                            max_batch_samples=batch_blocks * 131072 if batch_blocks else 1 << 20)
+    got = ch.process_stream_host(iq, batch_blocks) if batch_blocks else ch.process_host(iq)
+    assert first_mismatch(want, got.view(REC_DTYPE)) is None
+    st = ch.stats()
+    assert st["demod_accepted"] == [wst["accepted0"], wst["accepted1"], wst["accepted2"]]
+    assert st["demod_modeac"] == wst["modeac"]
+    if not batch_blocks:  # the magnitudes the demodulators saw are the table converter's
+        mag, _ = ch.batch_magnitudes(sc.n_samples, want_means=False)
+        assert np.array_equal(mag, Oracle(fmt=sc.fmt, q11_table_bits=bits).convert(iq)[0])
+    with pytest.raises(readsb_amd.RsbError, match="rsb_seek: not available with RSB_FLAG_SC16Q11_TABLE"):
+        ch.seek(0)
+    ch.close()
+
+
+def test_sc16q11_table_flag_is_refused_where_the_reference_has_no_such_converter(built, capfd):
+    # convert.c:451-456: the table stands in for SC16Q11 without the DC filter only
+    for kw in (dict(fmt="UC8"), dict(fmt="SC16"), dict(fmt="SC16Q11", dc_filter=True), dict(fmt="SC16Q11", q11_table_bits=12)):
+        with pytest.raises(readsb_amd.RsbError):
+            readsb_amd.Channel(**{"q11_table_bits": 8, **kw})
+    assert "RSB_FLAG_SC16Q11_TABLE" in capfd.readouterr().err
 
 
 @REPLAY

@@ -165,3 +165,28 @@ def test_reference_cli_prints_the_golden_lists(built):
     out = subprocess.run([sys.executable, os.path.join(root, "oracle", "pin_cli.py"), "cfg1_df11_df17", "nofix"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("IDENTICAL") == 2
+
+
+def test_oracle_sc16q11_table_build_matches_the_reference_built_that_way(built):
+    """convert_sc16q11_table (convert.c:264-328) exists only in a reference built with -DSC16Q11_TABLE_BITS=n.  The
+    fixtures come from oracle/_ref/ref_harness_t8 (n = 8): converter output and means bit for bit, and the message lists of two
+    scenarios (Mode A/C on: its noise thresholds use the integer means of that converter)."""
+    from scenarios import TABLE_CONVERT_CASES, TABLE_SCENARIOS
+
+    for name, (fmt, dc, n, chunk, bits) in TABLE_CONVERT_CASES.items():
+        iq = convert_input(fmt, n)
+        z = np.load(os.path.join(GOLD, f"convert_{name}.npz"))
+        o = Oracle(fmt=fmt, dc_filter=dc, q11_table_bits=bits)
+        parts = [o.convert(iq[pos:pos + chunk]) for pos in range(0, n, chunk)]
+        mag = np.concatenate([p[0] for p in parts])
+        assert hashlib.sha256(mag.tobytes()).digest() == bytes(z["mag_sha256"])
+        assert np.array_equal(np.array([(p[1], p[2]) for p in parts]), z["means"])
+        # and it is not the default build's converter
+        assert not np.array_equal(mag, np.concatenate([Oracle(fmt=fmt).convert(iq[pos:pos + chunk])[0] for pos in range(0, n, chunk)]))
+    for name, (sc, kw) in TABLE_SCENARIOS.items():
+        iq = generate(sc)
+        want, want_stats, sha = load_demod(name)
+        assert iq_sha256(iq) == sha
+        got, stats = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"], q11_table_bits=kw["q11_table_bits"]).run_stream(iq)
+        assert first_mismatch(want, got) is None
+        assert stats == want_stats
