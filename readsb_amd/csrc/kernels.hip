@@ -73,7 +73,15 @@ __device__ __forceinline__ uint32_t float_mag(float fI, float fQ) {
     // convert.c:236-243 (and :353-360): separately rounded products and sum, clamp, IEEE sqrt
     float magsq = fI * fI + fQ * fQ;
     if (magsq > 1.0f) magsq = 1.0f;
-    const float mag = sqrtf(magsq);
+    // sqrtf, correctly rounded, without the compiler's provisions for arguments this path never sees (it scales arguments below
+    // 2^-96 up and back and passes infinities through: 7 of its 16 instructions).  v_sqrt_f32 is within one ulp; the two
+    // residuals of its neighbours decide the rounding (the compiler's own sequence for the normal range).  Arguments here are 0
+    // or in [2^-30, 1] -- or, behind the DC filter, possibly tiny, where any result below 2^-17 gives magnitude 0 like the exact one.
+    const float r = __builtin_amdgcn_sqrtf(magsq);
+    const float r_dn = __uint_as_float(__float_as_uint(r) - 1u), r_up = __uint_as_float(__float_as_uint(r) + 1u);
+    const float e_dn = __builtin_fmaf(-r_dn, r, magsq), e_up = __builtin_fmaf(-r_up, r, magsq);
+    float mag = (e_dn <= 0.0f) ? r_dn : r;  // (r = 0: r_dn is a NaN, the comparison fails, 0 stays)
+    mag = (e_up > 0.0f) ? r_up : mag;
     return (uint32_t)(mag * 65535.0f + 0.5f);
 }
 
@@ -446,11 +454,19 @@ static_assert(sizeof(WaveShared) % 16 == 0, "per-wave LDS regions must keep 16-b
 // strip that reads one patches those samples from the full table.
 constexpr uint32_t kRadialSentinel = 0u ^ 0x8000u;  // magnitude 0, biased: the smallest int16
 
+// The repair tables of --fix (51 + 107 single-bit syndromes, crc.c:286-372) as the same open-addressed hash in LDS: 128 + 256 slots.
+// --aggressive's tables (1326 + 3831 entries) do not fit beside the strips and stay in global memory behind the Bloom filter.
+constexpr int kSynLdsSlots = 128 + 256;
+struct SynLds {
+    uint32_t keys[kSynLdsSlots], vals[kSynLdsSlots];
+};
+
 struct __attribute__((aligned(16))) ScanShared {
     uint16_t lut[kRadialEntries];
     uint32_t coef[10][16];           // [parity of e0 * 5 + trial phase - 4][3 v + dword]: negated tap pairs
     uint32_t bloom[2][kBloomWords];  // one bit per hashed syndrome of the 56- / 112-bit repair table: most lookups end here
     uint32_t gsyn[(12 + 23) * 32];   // per 5-bit group of a 56- / 112-bit frame: XOR of the single-bit syndromes of the set bits
+    SynLds syn;                      // --fix / --no-fix: the repair tables themselves
     WaveShared w[kScanWaves];
 };
 static_assert(kPasses >= 2 && kPasses <= 8 && kStrip / 8 > 64 * (kPasses - 1), "bit-sliced bytes hold up to 8 passes; the last pass must hold scan offsets");
@@ -570,8 +586,23 @@ __device__ __forceinline__ uint32_t sc16_pair(uint4 v, int which) {
 // whether any message bit is set.  combo << 27 | value, or kDeadItem.
 // One code path for 56- and 112-bit frames (lng is per lane): a wavefront that holds both kinds -- nearly every
 // one does -- then runs the Bloom test, the table lookup and the address repair once, not once per kind.
+__device__ __forceinline__ bool syn_tables_fit_lds(const DeviceTables &t) {
+    return (!t.syn_keys[0] || t.syn_mask[0] < 128u) && (!t.syn_keys[1] || t.syn_mask[1] < 256u);
+}
+__device__ __forceinline__ uint32_t diagnose_lds(const SynLds &T, const DeviceTables &t, int which, uint32_t syn) {
+    if (!t.syn_keys[which]) return 0xffffffffu;
+    const uint32_t mask = t.syn_mask[which], base = which ? 128u : 0u;
+    uint32_t h = syndrome_hash(syn, mask);
+    for (;;) {
+        const uint32_t k = T.keys[base + h];
+        if (k == syn) return T.vals[base + h];
+        if (k == 0) return 0xffffffffu;
+        h = (h + 1) & mask;
+    }
+}
+
 __device__ __forceinline__ uint32_t classify_fields(bool lng, uint32_t w0, uint32_t syn, bool nonzero, const DeviceTables &t, uint32_t *adders,
-                                                     const uint32_t (*bloom)[kBloomWords]) {
+                                                     const uint32_t (*bloom)[kBloomWords], const SynLds *syn_lds) {
     const uint32_t df = w0 >> 27, aa = w0 & 0xffffffu;
     if (!lng && !nonzero) return kDeadItem;  // all-zero message, mode_s.c:325
     // Address/Parity (DF0/4/5, DF16/24) and Comm-B (DF20/21: exact match or nothing, mode_s.c:391-403): the filter decides
@@ -583,7 +614,7 @@ __device__ __forceinline__ uint32_t classify_fields(bool lng, uint32_t w0, uint3
     if (s) {
         const uint32_t hb = bloom_bit(s);
         if (!((bloom[lng ? 1 : 0][hb >> 5] >> (hb & 31)) & 1u)) return kDeadItem;  // not in the table for sure
-        info = diagnose(t, lng ? 1 : 0, s);
+        info = syn_lds ? diagnose_lds(*syn_lds, t, lng ? 1 : 0, s) : diagnose(t, lng ? 1 : 0, s);
         if (info == kDeadItem || (!lng && (info & 0xff) > 1)) return kDeadItem;
     }
     const uint32_t addr = repair_aa(aa, info), e = info & 0xff;
@@ -601,6 +632,10 @@ __device__ __forceinline__ uint32_t from_next_lane(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
 }
 
+__device__ __forceinline__ uint32_t pk_add_sat_u16(uint32_t x, uint32_t y) {  // v_pk_add_u16 clamp: each half min(x + y, 65535)
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(ushort2v, x), __builtin_bit_cast(ushort2v, y)));
+}
 __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t x, uint32_t y) {  // v_pk_sub_i16 clamp: the sign bits are x < y per half
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(short2v, x), __builtin_bit_cast(short2v, y)));
 }
@@ -745,12 +780,18 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         sh.gsyn[i] = x;
     }
     __syncthreads();
+    const bool syn_in_lds = syn_tables_fit_lds(a.tab);  // uniform over the grid
+    const SynLds *syn_lds = syn_in_lds ? &sh.syn : nullptr;
     for (int which = 0; which < 2; ++which) {
         const uint32_t *keys = a.tab.syn_keys[which];
         if (!keys) continue;  // --no-fix: empty table, every non-zero syndrome is uncorrectable
         for (uint32_t i = tid; i <= a.tab.syn_mask[which]; i += kScanThreads) {
             const uint32_t k = keys[i];
             if (k) atomicOr(&sh.bloom[which][bloom_bit(k) >> 5], 1u << (bloom_bit(k) & 31));
+            if (syn_in_lds) {
+                sh.syn.keys[(which ? 128u : 0u) + i] = k;
+                sh.syn.vals[(which ? 128u : 0u) + i] = a.tab.syn_vals[which][i];
+            }
         }
     }
     __syncthreads();  // the last workgroup barrier: from here on every wavefront works alone
@@ -1150,7 +1191,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
             }
             syn = lng ? syn : syn_short;
             uint32_t cls = kDeadItem;
-            if (valid) cls = classify_fields(lng, w0, syn, nz != 0, a.tab, a.adder_bitmap, sh.bloom);
+            if (valid) cls = classify_fields(lng, w0, syn, nz != 0, a.tab, a.adder_bitmap, sh.bloom, syn_lds);
             const uint64_t em = __ballot(cls != kDeadItem);
             if (cls != kDeadItem) {
                 const uint32_t pos = nitems + lanes_below(em);
@@ -2118,9 +2159,12 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
     uint16_t *lut = sh.lut, *mt = sh.mt;
     uint64_t (*red)[kAcThreads / 64] = sh.red;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint64_t blk = blockIdx.x, blk_start = blk * kBlock;
-    const uint32_t blk_len = (uint32_t)((a.n - blk_start < (uint64_t)kBlock) ? (a.n - blk_start) : (uint64_t)kBlock);
     if constexpr (FMT == kFmtUC8) load_radial_table(lut, a.tab.uc8_radial, 0u, tid, kAcThreads);
+    // persistent: a workgroup takes every gridDim.x-th block, so the table is set up once per CU and not once per block
+    const uint64_t nblk = (a.n + kBlock - 1) / kBlock;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const uint64_t blk_start = blk * kBlock;
+    const uint32_t blk_len = (uint32_t)((a.n - blk_start < (uint64_t)kBlock) ? (a.n - blk_start) : (uint64_t)kBlock);
 
     // ---- pass 1: sum(mag), sum(mag^2) over the block's new samples iq[blk_start .. blk_start + blk_len)
     if (!a.block_means && !(a.debug_flags & 16)) {
@@ -2164,7 +2208,7 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
         }
         __syncthreads();
     }
-    if (sums_only || (a.debug_flags & 8)) return;
+    if (sums_only || (a.debug_flags & 8)) continue;
 
     // convert.c:104-110 then demod_2400.c:484-485
     const double mean_level = a.block_means ? a.block_means[2 * blk] : (double)red[0][0] / 65536.0 / (double)blk_len;
@@ -2175,6 +2219,9 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
     // ---- pass 2: tiles of kAcTile f1 positions; mt[i] = S[blk_start + t0 - 2 + i], i.e. m[j] = S[blk_start + t0 + j] = mt[j + 2]
     const uint16_t *m = mt + 2;
     const AcOut out{&a.counters[kCntAc], a.ac, a.ac_cap};
+    // F1 on packed pairs unless the block is so noisy that 4 * noise_level leaves 16 bits (workgroup-uniform)
+    const bool packed_f1 = noise_level <= 16383u && !(a.debug_flags & 512);
+    const uint32_t level_thr = ((4u * noise_level) ^ kBias) * 0x00010001u;
     for (uint32_t t0 = 0; t0 < blk_len; t0 += kAcTile) {
         const int64_t q0 = (int64_t)(blk_start + t0) - 2 - (int64_t)kTrailing;  // iq index of mt[0]: a multiple of 8
         if (a.iq_aligned && q0 >= 0 && q0 + 8 * kAcChunks <= (int64_t)a.n) {
@@ -2189,18 +2236,36 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
         // float steps (F2) and the 20-bit loop run on densely packed survivors of the whole tile.
         if (tid == 0) sh.nq1 = sh.nq2 = 0;
         __syncthreads();
+        uint32_t dbg_keep = 0;
         // F1 (:535-546), four consecutive positions per lane from one 16-byte window mt[4p .. 4p + 8) = m[4p - 2 .. 4p + 6)
         for (uint32_t p = tid; p < (uint32_t)kAcTile / 4; p += kAcThreads) {
             const uint2 lo = ((const uint2 *)mt)[p], hi = ((const uint2 *)mt)[p + 1];
-            const uint32_t v[8] = {lo.x & 0xffffu, lo.x >> 16, lo.y & 0xffffu, lo.y >> 16, hi.x & 0xffffu, hi.x >> 16, hi.y & 0xffffu, hi.y >> 16};
             uint32_t pass = 0;  // v[k + 2] = m[4p + k]
+            if (packed_f1) {
+                // two positions per instruction: D = sample pairs (v0,v1) .. (v6,v7), N = the pairs one sample on; '<' is the sign of a
+                // saturating packed subtraction of the biased values, the level test a saturating packed add against 4 * noise_level
+                // ((x + y) / 2 >= 2 n  <=>  x + y >= 4 n; the clamp at 65535 keeps that exact while 4 n <= 65535)
+                const uint32_t d0 = lo.x ^ kBias2, d1 = lo.y ^ kBias2, d2 = hi.x ^ kBias2, d3 = hi.y ^ kBias2;
+                const uint32_t n0 = __builtin_amdgcn_alignbit(d1, d0, 16), n1 = __builtin_amdgcn_alignbit(d2, d1, 16), n2 = __builtin_amdgcn_alignbit(d3, d2, 16);
+                const uint32_t s01 = pk_add_sat_u16(lo.y, n1 ^ kBias2) ^ kBias2, s23 = pk_add_sat_u16(hi.x, n2 ^ kBias2) ^ kBias2;
+                // positions 4p, 4p + 1: m[j-1] < m[j]: n0 < d1;  m[j+2] <= m[j]: !(d1 < d2);  m[j+2] <= m[j+1]: !(n1 < d2);  level: !(s01 < T)
+                const uint32_t r01 = pk_sub_sat(n0, d1) & ~(pk_sub_sat(d1, d2) | pk_sub_sat(n1, d2) | pk_sub_sat(s01, level_thr));
+                const uint32_t r23 = pk_sub_sat(n1, d2) & ~(pk_sub_sat(d2, d3) | pk_sub_sat(n2, d3) | pk_sub_sat(s23, level_thr));
+                pass = ((r01 >> 15) & 1u) | ((r01 >> 30) & 2u) | ((r23 >> 13) & 4u) | ((r23 >> 28) & 8u);
+                const unsigned f1_first = t0 + 4 * p;
+                if (f1_first == 0) pass &= ~1u;  // the loop starts at 1 (:487)
+                if (f1_first + 4 > blk_len) pass &= f1_first < blk_len ? (1u << (blk_len - f1_first)) - 1u : 0u;
+            } else {
+                const uint32_t v[8] = {lo.x & 0xffffu, lo.x >> 16, lo.y & 0xffffu, lo.y >> 16, hi.x & 0xffffu, hi.x >> 16, hi.y & 0xffffu, hi.y >> 16};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned f1_sample = t0 + 4 * p + k;
-                const bool ok = f1_sample != 0 && f1_sample < blk_len  // the loop starts at 1 (:487)
-                                && v[k + 1] < v[k + 2] && v[k + 4] <= v[k + 2] && v[k + 4] <= v[k + 3] && noise_level * 2 <= (v[k + 2] + v[k + 3]) / 2;
-                pass |= (uint32_t)ok << k;
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned f1_sample = t0 + 4 * p + k;
+                    const bool ok = f1_sample != 0 && f1_sample < blk_len  // the loop starts at 1 (:487)
+                                    && v[k + 1] < v[k + 2] && v[k + 4] <= v[k + 2] && v[k + 4] <= v[k + 3] && noise_level * 2 <= (v[k + 2] + v[k + 3]) / 2;
+                    pass |= (uint32_t)ok << k;
+                }
             }
+            if (a.debug_flags & 1024) { dbg_keep |= pass; continue; }
             // slots: one reservation per wavefront, the four sub-positions one after the other
             const uint64_t pm0 = __ballot(pass & 1u), pm1 = __ballot(pass & 2u), pm2 = __ballot(pass & 4u), pm3 = __ballot(pass & 8u);
             const uint32_t c0 = (uint32_t)__popcll(pm0), c1 = (uint32_t)__popcll(pm1), c2 = (uint32_t)__popcll(pm2), total = c0 + c1 + c2 + (uint32_t)__popcll(pm3);
@@ -2219,6 +2284,7 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
                     ac_bits(out, m, j, t0 + j, blk_start, noise_level);
             }
         }
+        if ((a.debug_flags & 1024) && dbg_keep == 0xdeadbeefu) sh.q2[tid] = 1;
         __syncthreads();
         if (a.debug_flags & 64) continue;
         const uint32_t nq1 = min(sh.nq1, (uint32_t)kAcQ1);
@@ -2251,6 +2317,7 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
             ac_bits(out, m, j, t0 + j, blk_start, noise_level);
         }
         __syncthreads();
+    }
     }
 }
 
@@ -2859,7 +2926,15 @@ static hipError_t launch_ac_kernel(const BatchArgs &a, int sums_only, hipStream_
     auto kern = k_modeac<FMT>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AcShared));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((a.n + kBlock - 1) / kBlock)), dim3(kAcThreads), sizeof(AcShared), s, a, sums_only);
+    // one workgroup per CU (its LDS allows no second one), each walking the blocks with that stride
+    int dev = 0, cus = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+    static const int forced = std::getenv("RSB_AC_GRID") ? std::atoi(std::getenv("RSB_AC_GRID")) : 0;  // A/B timing only
+    const uint64_t nblk = (a.n + kBlock - 1) / kBlock;
+    uint64_t grid = forced > 0 ? (uint64_t)forced : (uint64_t)(cus > 0 ? cus : 256);
+    if (grid > nblk) grid = nblk;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kAcThreads), sizeof(AcShared), s, a, sums_only);
     return hipGetLastError();
 }
 
