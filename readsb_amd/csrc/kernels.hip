@@ -69,19 +69,24 @@ constexpr int kThreads = 256;
 // ------------------------------------------------------------------------------------------------
 // sample -> magnitude
 
+// sqrtf, correctly rounded, without the compiler's provisions for arguments this path never sees (it scales arguments below
+// 2^-96 up and back and passes infinities through: 7 of its 16 instructions).  v_sqrt_f32 is within one ulp; the two
+// residuals of its neighbours decide the rounding (the compiler's own sequence for the normal range).  Arguments here are 0
+// or in [2^-30, 1] -- or, behind the DC filter, possibly tiny, where any result below 2^-17 gives magnitude 0 like the exact one.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    const float r = __builtin_amdgcn_sqrtf(x);
+    const float r_dn = __uint_as_float(__float_as_uint(r) - 1u), r_up = __uint_as_float(__float_as_uint(r) + 1u);
+    const float e_dn = __builtin_fmaf(-r_dn, r, x), e_up = __builtin_fmaf(-r_up, r, x);
+    float y = (e_dn <= 0.0f) ? r_dn : r;  // (r = 0: r_dn is a NaN, the comparison fails, 0 stays)
+    y = (e_up > 0.0f) ? r_up : y;
+    return y;
+}
+
 __device__ __forceinline__ uint32_t float_mag(float fI, float fQ) {
     // convert.c:236-243 (and :353-360): separately rounded products and sum, clamp, IEEE sqrt
     float magsq = fI * fI + fQ * fQ;
     if (magsq > 1.0f) magsq = 1.0f;
-    // sqrtf, correctly rounded, without the compiler's provisions for arguments this path never sees (it scales arguments below
-    // 2^-96 up and back and passes infinities through: 7 of its 16 instructions).  v_sqrt_f32 is within one ulp; the two
-    // residuals of its neighbours decide the rounding (the compiler's own sequence for the normal range).  Arguments here are 0
-    // or in [2^-30, 1] -- or, behind the DC filter, possibly tiny, where any result below 2^-17 gives magnitude 0 like the exact one.
-    const float r = __builtin_amdgcn_sqrtf(magsq);
-    const float r_dn = __uint_as_float(__float_as_uint(r) - 1u), r_up = __uint_as_float(__float_as_uint(r) + 1u);
-    const float e_dn = __builtin_fmaf(-r_dn, r, magsq), e_up = __builtin_fmaf(-r_up, r, magsq);
-    float mag = (e_dn <= 0.0f) ? r_dn : r;  // (r = 0: r_dn is a NaN, the comparison fails, 0 stays)
-    mag = (e_up > 0.0f) ? r_up : mag;
+    const float mag = sqrt_rn(magsq);
     return (uint32_t)(mag * 65535.0f + 0.5f);
 }
 
@@ -1961,13 +1966,22 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
 
 // The same sums for many blocks at once.  The sequential part is two float additions per sample and block; k_block_means_float
 // spends a whole wavefront on one block's chain (v_readlane + v_add per sample: 64 blocks' chains would fit its lanes).  Here a
-// workgroup takes 60 blocks: wavefront 0 holds one block per lane and adds, in sample order, what wavefronts 1..15 computed
-// 64 samples ahead into LDS (transposed: [sample][block], row stride 61 floats = no bank conflicts on either side).
-constexpr int kMeansGroup = 60, kMeansChunk = 64, kMeansRow = 61;
+// workgroup takes 16 blocks: wavefront 0 holds one block per lane and adds, in sample order, what wavefronts 1..4 computed 64
+// samples ahead into LDS.  What bounds the chain is the rate at which ONE wavefront issues instructions (one per 5-9 cycles,
+// profiles/r2_valu_issue_cost.txt), not its lanes, so: both sums of a sample in one v_pk_add_f32, two samples' (mag, magsq) pairs
+// per ds_read_b128 -- 1.5 instructions per sample in place of 4 -- and small groups, so that 512 chains run side by side (two
+// workgroups per CU) and the converting wavefronts (the VALU work: ~20 instructions per sample) have every SIMD of the chip.
+// LDS layout: [pair of samples][block] units of 16 bytes {mag0, magsq0, mag1, magsq1}, 17 units per row: the adder's 16 lanes
+// read one contiguous row, a converting wavefront's lane pairs write 8-byte halves 272 bytes apart (every bank once per 8 pairs).
+constexpr int kMeansGroup = 16, kMeansChunk = 256, kMeansRow = 17, kMeansProducers = kMeansGroup / 4, kMeansThreads = 64 * (1 + kMeansProducers);
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+constexpr size_t kMeansLds = 2 * (size_t)(kMeansChunk / 2) * kMeansRow * sizeof(float4v);
 template <int FMT>
-__global__ __launch_bounds__(1024) void k_block_means_group(const void *iq, uint64_t n, uint64_t blk_len, double *means, uint32_t nblocks) {
+__global__ __launch_bounds__(kMeansThreads) void k_block_means_group(const void *iq, uint64_t n, uint64_t blk_len, double *means, uint32_t nblocks) {
     if constexpr (FMT == kFmtSC16 || FMT == kFmtSC16Q11) {
-        __shared__ float buf[2][2][kMeansChunk * kMeansRow];  // [buffer][0 = mag, 1 = magsq][sample * kMeansRow + block]
+        extern __shared__ __attribute__((aligned(16))) unsigned char means_lds[];
+        float4v (*buf)[(kMeansChunk / 2) * kMeansRow] = reinterpret_cast<float4v (*)[(kMeansChunk / 2) * kMeansRow]>(means_lds);
         const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const uint32_t b0 = blockIdx.x * kMeansGroup;
         const uint32_t nchunks = (uint32_t)((blk_len + kMeansChunk - 1) / kMeansChunk);
@@ -1977,61 +1991,93 @@ __global__ __launch_bounds__(1024) void k_block_means_group(const void *iq, uint
             const uint64_t start = (uint64_t)blk * blk_len;
             return (uint32_t)((n - start < blk_len) ? (n - start) : blk_len);
         };
-        // wavefronts 1..15, four blocks each: the raw samples of a chunk are fetched four chunks ahead (slot = chunk % 4), so that
-        // no iteration waits for HBM; zero samples (beyond a block's end) give mag = magsq = 0
-        uint32_t pre[4][4];
+        // wavefronts 1..4, four blocks each, four consecutive samples per lane and block in one 16-byte load (1 KB per wavefront
+        // and block: every trip to HBM brings 256 samples of a block), fetched two chunks ahead; zero samples (beyond a block's
+        // end) give mag = magsq = 0
+        const bool vec = (uintptr_t)iq % 16 == 0 && blk_len % 4 == 0;
+        uint4 pre[2][4];
         auto fetch = [&](uint32_t c, int slot) {
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) {
-                const uint32_t blk = b0 + (wave - 1) * 4 + q, s = c * kMeansChunk + lane;
-                pre[slot][q] = (s < length_of(blk)) ? ((const uint32_t *)iq)[(uint64_t)blk * blk_len + s] : 0u;
+                const uint32_t blk = b0 + (wave - 1) * 4 + q, s = c * kMeansChunk + 4 * lane, len = length_of(blk);
+                const uint32_t *src = (const uint32_t *)iq + (uint64_t)blk * blk_len + s;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (vec && s + 4 <= len) {
+                    v = *(const uint4 *)src;
+                } else if (s < len) {
+                    v.x = src[0];
+                    if (s + 1 < len) v.y = src[1];
+                    if (s + 2 < len) v.z = src[2];
+                    if (s + 3 < len) v.w = src[3];
+                }
+                pre[slot][q] = v;
             }
+        };
+        auto mags = [&](uint32_t v) {
+            const float fI = (float)(short)(v & 0xffffu) * scale, fQ = (float)(short)(v >> 16) * scale;
+            float magsq = fI * fI + fQ * fQ;  // convert.c:236-243
+            if (magsq > 1.0f) magsq = 1.0f;
+            float2v o;
+            o.x = sqrt_rn(magsq);
+            o.y = magsq;
+            return o;
         };
         auto emit = [&](int slot, uint32_t which) {
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) {
-                const uint32_t lb = (wave - 1) * 4 + q, v = pre[slot][q];
-                const float fI = (float)(short)(v & 0xffffu) * scale, fQ = (float)(short)(v >> 16) * scale;
-                float magsq = fI * fI + fQ * fQ;  // convert.c:236-243
-                if (magsq > 1.0f) magsq = 1.0f;
-                buf[which][0][lane * kMeansRow + lb] = sqrtf(magsq);
-                buf[which][1][lane * kMeansRow + lb] = magsq;
+                const uint32_t lb = (wave - 1) * 4 + q;
+                const uint4 v = pre[slot][q];
+                float4v lo, hi;
+                lo.xy = mags(v.x);
+                lo.zw = mags(v.y);
+                hi.xy = mags(v.z);
+                hi.zw = mags(v.w);
+                buf[which][(2 * lane) * kMeansRow + lb] = lo;
+                buf[which][(2 * lane + 1) * kMeansRow + lb] = hi;
             }
         };
         const uint32_t my_len = length_of(b0 + lane);  // wavefront 0: lane = block
-        float sum_level = 0, sum_power = 0;
+        float2v sums = {0.0f, 0.0f};                   // {sum_level, sum_power}: v_pk_add_f32 rounds each half like v_add_f32
         auto consume = [&](uint32_t c) {
-            const float *mg = &buf[c & 1][0][lane], *pw = &buf[c & 1][1][lane];
+            const float4v *row = &buf[c & 1][lane];
             const uint32_t s0 = c * kMeansChunk;
             if (s0 + kMeansChunk <= my_len) {
-#pragma unroll 16
-                for (uint32_t k = 0; k < (uint32_t)kMeansChunk; ++k) {  // convert.c:226-262: sample order
-                    sum_power += pw[k * kMeansRow];
-                    sum_level += mg[k * kMeansRow];
+                // convert.c:226-262: sample order.  Reads run kDepth pairs ahead of the additions (left to the compiler, every
+                // read is waited for right before its two additions: one LDS round trip per pair of samples)
+                constexpr int kDepth = 8;
+                float4v q[kDepth];
+#pragma unroll
+                for (int k = 0; k < kDepth; ++k) q[k] = row[k * kMeansRow];
+                for (uint32_t k0 = 0; k0 < (uint32_t)kMeansChunk / 2; k0 += kDepth) {
+#pragma unroll
+                    for (int k = 0; k < kDepth; ++k) {
+                        const float4v x = q[k];
+                        if (k0 + kDepth < (uint32_t)kMeansChunk / 2) q[k] = row[(k0 + kDepth + k) * kMeansRow];
+                        sums += x.xy;
+                        sums += x.zw;
+                    }
                 }
             } else {
                 for (uint32_t k = 0; k < (uint32_t)kMeansChunk && s0 + k < my_len; ++k) {
-                    sum_power += pw[k * kMeansRow];
-                    sum_level += mg[k * kMeansRow];
+                    const float4v v = row[(k >> 1) * kMeansRow];
+                    sums += (k & 1) ? v.zw : v.xy;
                 }
             }
         };
         if (wave >= 1) {
             fetch(0, 0);
             fetch(1, 1);
-            fetch(2, 2);
-            fetch(3, 3);
             emit(0, 0);
-            fetch(4, 0);
+            fetch(2, 0);
         }
         __syncthreads();
-        for (uint32_t c = 0; c < nchunks; c += 4) {  // iteration i = c + u: chunk i + 1 goes to LDS while chunk i is added
+        for (uint32_t c = 0; c < nchunks; c += 2) {  // iteration i = c + u: chunk i + 1 goes to LDS while chunk i is added
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 const uint32_t i = c + (uint32_t)u;
                 if (wave >= 1) {
-                    emit((u + 1) & 3, (i + 1) & 1);
-                    fetch(i + 5, (u + 1) & 3);
+                    emit((u + 1) & 1, (i + 1) & 1);
+                    fetch(i + 3, (u + 1) & 1);
                 } else if (lane < (uint32_t)kMeansGroup && i < nchunks) {
                     consume(i);
                 }
@@ -2039,8 +2085,8 @@ __global__ __launch_bounds__(1024) void k_block_means_group(const void *iq, uint
             }
         }
         if (wave == 0 && lane < (uint32_t)kMeansGroup && b0 + lane < nblocks) {  // "sum / nsamples" is a float division there, widened afterwards
-            means[2 * (b0 + lane)] = (double)(sum_level / (float)my_len);
-            means[2 * (b0 + lane) + 1] = (double)(sum_power / (float)my_len);
+            means[2 * (b0 + lane)] = (double)(sums.x / (float)my_len);
+            means[2 * (b0 + lane) + 1] = (double)(sums.y / (float)my_len);
         }
     }
 }
@@ -2338,7 +2384,7 @@ __global__ __launch_bounds__(64) void k_block_means_float(const void *iq, uint64
                 const float fI = (float)v.x * scale, fQ = (float)v.y * scale;
                 magsq = fI * fI + fQ * fQ;
                 if (magsq > 1.0f) magsq = 1.0f;
-                mag = sqrtf(magsq);
+                mag = sqrt_rn(magsq);
             }
             const uint32_t cnt = (len - base < 64u) ? (len - base) : 64u;
             if (cnt == 64) {
@@ -2527,42 +2573,75 @@ __global__ __launch_bounds__(kThreads) void k_dc_tile_sums(const void *iq, uint6
     if (threadIdx.x == kThreads - 1) tile_sums[blockIdx.x] = v.incl;
 }
 
-// phase 2: state at the start of every tile; state[0] = the carried-in state, state[ntiles] = the state to carry out
-__global__ __launch_bounds__(1024) void k_dc_scan_tiles(const double2 *tile_sums, double2 *tile_start, uint32_t ntiles, const double2 *z_in, double dc_b) {
-    __shared__ double2 part[1024];
-    __shared__ double mpow[1024];
-    const uint32_t t = threadIdx.x, per = (ntiles + 1023) / 1024, lo = t * per, hi = min(ntiles, lo + per);
+// phase 2: state at the start of every tile; state[0] = the carried-in state, state[ntiles] = the state to carry out.
+// Two launches over chunks of 1024 tiles (one workgroup each; round 2's single workgroup walked 256 tiles per thread with
+// 4 KB between neighbouring lanes' loads and took 0.56 ms per Gsample): (a) scan of the chunk's tiles from a zero state ->
+// tile_start[i] relative to the chunk's start, the chunk's total into the chunk's first tile_sums entry (already consumed);
+// (b) every workgroup runs the (<= 1024) chunk totals before it to its own starting state and adds that state's decay.
+constexpr int kDcChunkTiles = 1024;
+__device__ __forceinline__ double dc_tile_multiplier(double dc_b) {
     double mt = dc_b;
     for (int k = 0; k < 12; ++k) mt *= mt;  // dc_b^4096: one tile
-    // this thread's run of tiles from a zero state, and the multiplier of the run
-    double zI = 0, zQ = 0, m = 1;
-    for (uint32_t i = lo; i < hi; ++i) {
-        zI = zI * mt + tile_sums[i].x;
-        zQ = zQ * mt + tile_sums[i].y;
-        m *= mt;
-    }
-    part[t] = make_double2(zI, zQ);
-    mpow[t] = m;
-    __syncthreads();
-    if (t == 0) {  // 1024 sequential steps: state at the start of every thread's run
-        double2 z = *z_in;
-        for (uint32_t u = 0; u < 1024; ++u) {
-            const double2 own = part[u];
-            part[u] = z;
-            z.x = z.x * mpow[u] + own.x;
-            z.y = z.y * mpow[u] + own.y;
-        }
-    }
-    __syncthreads();
-    double2 z = part[t];
-    for (uint32_t i = lo; i < hi; ++i) {
-        tile_start[i] = z;
-        z.x = z.x * mt + tile_sums[i].x;
-        z.y = z.y * mt + tile_sums[i].y;
-    }
-    if (hi == ntiles && lo < hi) tile_start[ntiles] = z;
-    if (ntiles == 0 && t == 0) tile_start[0] = *z_in;
+    return mt;
 }
+static_assert(kDcTile == 4096, "dc_tile_multiplier squares twelve times");
+
+__global__ __launch_bounds__(kDcChunkTiles) void k_dc_scan_local(double2 *tile_sums, double2 *tile_start, uint32_t ntiles, double dc_b) {
+    __shared__ double2 sh[kDcChunkTiles];
+    const uint32_t t = threadIdx.x, first = blockIdx.x * kDcChunkTiles, i = first + t;
+    double2 own = i < ntiles ? tile_sums[i] : make_double2(0, 0);
+    sh[t] = own;
+    __syncthreads();
+    double w = dc_tile_multiplier(dc_b);
+    for (uint32_t d = 1; d < (uint32_t)kDcChunkTiles; d <<= 1) {  // own = sum_{u <= t} mt^(t-u) sums[first + u]
+        double2 add = make_double2(0, 0);
+        if (t >= d) add = sh[t - d];
+        __syncthreads();
+        if (t >= d) {
+            own.x += w * add.x;
+            own.y += w * add.y;
+            sh[t] = own;
+        }
+        __syncthreads();
+        w *= w;
+    }
+    if (i < ntiles) tile_start[i] = t ? sh[t - 1] : make_double2(0, 0);
+    const uint32_t live = ntiles - first < (uint32_t)kDcChunkTiles ? ntiles - first : (uint32_t)kDcChunkTiles;
+    if (t == live - 1) tile_sums[first] = own;  // the chunk from a zero state, after its last tile
+}
+
+__global__ __launch_bounds__(kDcChunkTiles) void k_dc_scan_finish(const double2 *tile_sums, double2 *tile_start, uint32_t ntiles, const double2 *z_in, double dc_b) {
+    __shared__ double2 tot[kDcChunkTiles];
+    __shared__ double2 zc;
+    const uint32_t t = threadIdx.x, g = blockIdx.x, first = g * kDcChunkTiles, i = first + t;
+    if (t < g) tot[t] = tile_sums[(size_t)t * kDcChunkTiles];  // (at most 1024 chunks: 2^32 samples)
+    __syncthreads();
+    const double mt = dc_tile_multiplier(dc_b);
+    if (t == 0) {
+        double mc = mt;
+        for (int k = 0; k < 10; ++k) mc *= mc;  // mt^1024: one chunk
+        double2 z = *z_in;
+        for (uint32_t u = 0; u < g; ++u) {
+            z.x = z.x * mc + tot[u].x;
+            z.y = z.y * mc + tot[u].y;
+        }
+        zc = z;
+    }
+    __syncthreads();
+    double carry = 1.0, sq = mt;  // mt^t by the bits of t
+    for (uint32_t k = t; k; k >>= 1, sq *= sq)
+        if (k & 1) carry *= sq;
+    const double2 z0 = zc;
+    if (i < ntiles) {
+        const double2 local = tile_start[i];
+        tile_start[i] = make_double2(z0.x * carry + local.x, z0.y * carry + local.y);
+    }
+    if (g == gridDim.x - 1 && t == ntiles - first - 1) {  // the state to carry out: after the last tile
+        const double2 last = tile_sums[first];
+        tile_start[ntiles] = make_double2(z0.x * carry * mt + last.x, z0.y * carry * mt + last.y);
+    }
+}
+static_assert(0xfffff000ull / kDcTile / kDcChunkTiles < (unsigned long long)kDcChunkTiles, "k_dc_scan_finish holds every chunk total of the largest batch");
 
 // phase 3: magnitudes.  sums (optional): per 131072-sample block of this call, sum(mag) and sum(magsq) as doubles.
 template <int FMT>
@@ -2615,7 +2694,7 @@ __global__ __launch_bounds__(kThreads) void k_convert_dc(const void *iq, uint16_
         xQ -= z1_Q;
         float magsq = xI * xI + xQ * xQ;
         if (magsq > 1.0f) magsq = 1.0f;
-        const float m = (abl & 4) ? magsq : sqrtf(magsq);
+        const float m = (abl & 4) ? magsq : sqrt_rn(magsq);
         const uint32_t mv = (uint32_t)(uint16_t)(m * 65535.0f + 0.5f);
         packed[k >> 1] = (k & 1) ? (packed[k >> 1] | (mv << 16)) : mv;
         if (!tile_out && k < live) mag[first + k] = (uint16_t)mv;
@@ -2913,9 +2992,12 @@ hipError_t launch_block_means_float(int fmt, const void *iq, uint64_t n, uint64_
     if (n == 0) return hipSuccess;
     const uint32_t nblocks = (uint32_t)((n + blk_len - 1) / blk_len);
     return by_format(fmt, [&](auto F) {
-        if (nblocks >= 16)  // many blocks: one lane per block does the sequential sums, the other wavefronts feed it
-            hipLaunchKernelGGL(k_block_means_group<decltype(F)::value>, dim3((nblocks + kMeansGroup - 1) / kMeansGroup), dim3(1024), 0, s, iq, n, blk_len, means, nblocks);
-        else
+        if (nblocks >= 16) {  // many blocks: one lane per block does the sequential sums, the other wavefronts feed it
+            auto kern = k_block_means_group<decltype(F)::value>;
+            const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMeansLds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3((nblocks + kMeansGroup - 1) / kMeansGroup), dim3(kMeansThreads), kMeansLds, s, iq, n, blk_len, means, nblocks);
+        } else
             hipLaunchKernelGGL(k_block_means_float<decltype(F)::value>, dim3(nblocks), dim3(64), 0, s, iq, n, blk_len, means);
         return hipGetLastError();
     });
@@ -2968,7 +3050,9 @@ hipError_t launch_convert_dc(int fmt, const void *iq, uint16_t *mag, uint64_t n,
             if (block_means) e = hipMemsetAsync(block_means, 0, (size_t)nblocks * 2 * sizeof(double), s);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(k_dc_tile_sums<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, n, (double)dc_a, (double)dc_b, tile_sums);
-            hipLaunchKernelGGL(k_dc_scan_tiles, dim3(1), dim3(1024), 0, s, tile_sums, tile_start, ntiles, z_state, (double)dc_b);
+            const uint32_t nchunks = (ntiles + kDcChunkTiles - 1) / kDcChunkTiles;
+            hipLaunchKernelGGL(k_dc_scan_local, dim3(nchunks), dim3(kDcChunkTiles), 0, s, tile_sums, tile_start, ntiles, (double)dc_b);
+            hipLaunchKernelGGL(k_dc_scan_finish, dim3(nchunks), dim3(kDcChunkTiles), 0, s, tile_sums, tile_start, ntiles, z_state, (double)dc_b);
             static const int abl = std::getenv("RSB_DC_ABL") ? std::atoi(std::getenv("RSB_DC_ABL")) : 0;  // ablation timing only
             hipLaunchKernelGGL(k_convert_dc<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, mag, n, dc_a, dc_b, tile_start, block_means, z_state, abl);
             if (block_means) hipLaunchKernelGGL(k_dc_means, dim3((nblocks + 255) / 256), dim3(256), 0, s, block_means, n, nblocks);
