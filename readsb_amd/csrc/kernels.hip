@@ -2282,10 +2282,12 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
         // float steps (F2) and the 20-bit loop run on densely packed survivors of the whole tile.
         if (tid == 0) sh.nq1 = sh.nq2 = 0;
         __syncthreads();
-        uint32_t dbg_keep = 0;
-        // F1 (:535-546), four consecutive positions per lane from one 16-byte window mt[4p .. 4p + 8) = m[4p - 2 .. 4p + 6)
-        for (uint32_t p = tid; p < (uint32_t)kAcTile / 4; p += kAcThreads) {
-            const uint2 lo = ((const uint2 *)mt)[p], hi = ((const uint2 *)mt)[p + 1];
+        // F1 (:535-546), four consecutive positions per lane and step from one 16-byte window mt[4p .. 4p + 8) = m[4p - 2 .. 4p + 6).
+        // All of a lane's windows of the tile are read first and its 32 results kept in one word; then ONE queue reservation per
+        // wavefront and tile (round 2 reserved per step: eight LDS atomics with their round trips in a row, 0.27 ms per Gsample).
+        constexpr int kF1Steps = kAcTile / 4 / kAcThreads;
+        static_assert(kF1Steps * 4 == 32 && kF1Steps * 4 * kAcThreads == kAcTile, "a lane's F1 results of a tile fill one 32-bit word");
+        auto f1_pass = [&](const uint2 lo, const uint2 hi, const uint32_t p) -> uint32_t {
             uint32_t pass = 0;  // v[k + 2] = m[4p + k]
             if (packed_f1) {
                 // two positions per instruction: D = sample pairs (v0,v1) .. (v6,v7), N = the pairs one sample on; '<' is the sign of a
@@ -2311,26 +2313,43 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
                     pass |= (uint32_t)ok << k;
                 }
             }
-            if (a.debug_flags & 1024) { dbg_keep |= pass; continue; }
-            // slots: one reservation per wavefront, the four sub-positions one after the other
-            const uint64_t pm0 = __ballot(pass & 1u), pm1 = __ballot(pass & 2u), pm2 = __ballot(pass & 4u), pm3 = __ballot(pass & 8u);
-            const uint32_t c0 = (uint32_t)__popcll(pm0), c1 = (uint32_t)__popcll(pm1), c2 = (uint32_t)__popcll(pm2), total = c0 + c1 + c2 + (uint32_t)__popcll(pm3);
-            if (total == 0) continue;
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&sh.nq1, total);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            const uint32_t slots[4] = {base + lanes_below(pm0), base + c0 + lanes_below(pm1), base + c0 + c1 + lanes_below(pm2), base + c0 + c1 + c2 + lanes_below(pm3)};
+            return pass;
+        };
+        uint32_t f1_bits = 0;  // bit 4 s + k: position 4 (tid + s * kAcThreads) + k of the tile
+        {
+            uint2 win[kF1Steps][2];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!((pass >> k) & 1u)) continue;
-                const uint32_t j = 4 * p + k;
-                if (slots[k] < (uint32_t)kAcQ1)
-                    sh.q1[slots[k]] = (uint16_t)j;
-                else if (ac_f2_tests(m, j, t0 + j, noise_level))  // queue full: on the spot
-                    ac_bits(out, m, j, t0 + j, blk_start, noise_level);
+            for (int st = 0; st < kF1Steps; ++st) {
+                win[st][0] = ((const uint2 *)mt)[tid + st * kAcThreads];
+                win[st][1] = ((const uint2 *)mt)[tid + st * kAcThreads + 1];
+            }
+#pragma unroll
+            for (int st = 0; st < kF1Steps; ++st) f1_bits |= f1_pass(win[st][0], win[st][1], tid + st * kAcThreads) << (4 * st);
+        }
+        if (!(a.debug_flags & 1024)) {
+            // this lane's first slot: the counts (0..32) of the lanes below, bit plane by bit plane
+            const uint32_t cnt = (uint32_t)__popc(f1_bits);
+            uint32_t below = 0, total = 0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const uint64_t plane = __ballot((cnt >> b) & 1u);
+                below += lanes_below(plane) << b;
+                total += (uint32_t)__popcll(plane) << b;
+            }
+            if (total) {  // wave-uniform
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&sh.nq1, total);
+                uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + below;
+                for (uint32_t rest = f1_bits; rest; rest &= rest - 1, ++slot) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(rest), j = 4 * (tid + (b >> 2) * kAcThreads) + (b & 3u);
+                    if (slot < (uint32_t)kAcQ1)
+                        sh.q1[slot] = (uint16_t)j;
+                    else if (ac_f2_tests(m, j, t0 + j, noise_level))  // queue full: on the spot
+                        ac_bits(out, m, j, t0 + j, blk_start, noise_level);
+                }
             }
         }
-        if ((a.debug_flags & 1024) && dbg_keep == 0xdeadbeefu) sh.q2[tid] = 1;
+        if ((a.debug_flags & 1024) && f1_bits == 0xdeadbeefu) sh.q2[tid] = 1;  // (ablation: the tests alone)
         __syncthreads();
         if (a.debug_flags & 64) continue;
         const uint32_t nq1 = min(sh.nq1, (uint32_t)kAcQ1);
