@@ -2223,10 +2223,32 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
         uint32_t done = 0;
         if (a.iq_aligned) {
             const uint32_t nch = blk_len / 8;
-            for (uint32_t c = tid; c < nch; c += kAcThreads) {
-                const uint4 o = ac_chunk<FMT>(a.iq, (int64_t)(blk_start / 8 + c), lut, a.tab.uc8_lut);
+            auto take8 = [&](const uint4 o) {
                 take(o.x & 0xffffu); take(o.x >> 16); take(o.y & 0xffffu); take(o.y >> 16);
                 take(o.z & 0xffffu); take(o.z >> 16); take(o.w & 0xffffu); take(o.w >> 16);
+            };
+            constexpr int kFull = kBlock / 8 / kAcThreads;  // chunks per thread of a whole block
+            if ((FMT == kFmtUC8 || FMT == kFmtMag16) && blk_len == (uint32_t)kBlock) {
+                // a whole block of a 2-byte format: all of the thread's 16-byte loads go out before the first is used (in the
+                // loop below every load is waited for at its use: sixteen trips to memory one after the other)
+                const uint4 *src = (const uint4 *)a.iq + blk_start / 8 + tid;
+                constexpr int kBatch = 8;  // (all sixteen at once: 64 registers, and the 1024-thread workgroup's 128 run out)
+                static_assert(kFull % kBatch == 0, "whole batches");
+#pragma unroll 1
+                for (int k0 = 0; k0 < kFull; k0 += kBatch) {
+                    uint4 raw[kBatch];
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) raw[k] = src[(k0 + k) * kAcThreads];
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        if constexpr (FMT == kFmtUC8)
+                            take8(uc8_chunk_radial_exact<0u>(raw[k], (uint32_t)(uintptr_t)lut, a.tab.uc8_lut));
+                        else
+                            take8(raw[k]);
+                    }
+                }
+            } else {
+                for (uint32_t c = tid; c < nch; c += kAcThreads) take8(ac_chunk<FMT>(a.iq, (int64_t)(blk_start / 8 + c), lut, a.tab.uc8_lut));
             }
             done = nch * 8;
         }
@@ -2271,7 +2293,27 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
     for (uint32_t t0 = 0; t0 < blk_len; t0 += kAcTile) {
         const int64_t q0 = (int64_t)(blk_start + t0) - 2 - (int64_t)kTrailing;  // iq index of mt[0]: a multiple of 8
         if (a.iq_aligned && q0 >= 0 && q0 + 8 * kAcChunks <= (int64_t)a.n) {
-            for (uint32_t c = tid; c < (uint32_t)kAcChunks; c += kAcThreads) ((uint4 *)mt)[c] = ac_chunk<FMT>(a.iq, q0 / 8 + c, lut, a.tab.uc8_lut);
+            if constexpr (FMT == kFmtUC8 || FMT == kFmtMag16) {  // the thread's loads of the tile first, then the conversions
+                constexpr int kLoads = (kAcChunks + kAcThreads - 1) / kAcThreads;
+                const uint4 *src = (const uint4 *)a.iq + q0 / 8;
+                uint4 raw[kLoads];
+#pragma unroll
+                for (int k = 0; k < kLoads; ++k) {
+                    const uint32_t c = tid + (uint32_t)k * kAcThreads;
+                    raw[k] = src[c < (uint32_t)kAcChunks ? c : (uint32_t)kAcChunks - 1];
+                }
+#pragma unroll
+                for (int k = 0; k < kLoads; ++k) {
+                    const uint32_t c = tid + (uint32_t)k * kAcThreads;
+                    if (c >= (uint32_t)kAcChunks) break;
+                    if constexpr (FMT == kFmtUC8)
+                        ((uint4 *)mt)[c] = uc8_chunk_radial_exact<0u>(raw[k], (uint32_t)(uintptr_t)lut, a.tab.uc8_lut);
+                    else
+                        ((uint4 *)mt)[c] = raw[k];
+                }
+            } else {
+                for (uint32_t c = tid; c < (uint32_t)kAcChunks; c += kAcThreads) ((uint4 *)mt)[c] = ac_chunk<FMT>(a.iq, q0 / 8 + c, lut, a.tab.uc8_lut);
+            }
         } else {  // the batch's first tile (carry), its last ones (end of the stream), unaligned input
             for (uint32_t i = tid; i < 8u * kAcChunks; i += kAcThreads) mt[i] = (uint16_t)stream_mag<FMT>(a, q0 + (int64_t)kTrailing + i);
         }
