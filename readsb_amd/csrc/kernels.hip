@@ -1735,6 +1735,12 @@ __global__ __launch_bounds__(kThreads) void k_filter_fill(uint32_t *t0, uint32_t
 #ifndef RSB_EMIT_WAVES
 #define RSB_EMIT_WAVES 8
 #endif
+#ifndef RSB_EMIT_FLIGHT
+#define RSB_EMIT_FLIGHT 2
+#endif
+#ifndef RSB_EMIT_BURST
+#define RSB_EMIT_BURST 0
+#endif
 #ifndef RSB_EMIT_GROUPS
 #define RSB_EMIT_GROUPS 512
 #endif
@@ -1803,7 +1809,8 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
         const int64_t sd = e0 - (int64_t)par;
         const bool direct = a.iq_aligned && sd >= 0 && sd + 24 * ntrios <= (int64_t)a.n;
         const uint4_a4 *src = (const uint4_a4 *)((const uint8_t *)a.iq + kBps * sd);
-        uint4 raw[2][3][kRawVecs];  // two trios in flight
+        constexpr int kFlight = RSB_EMIT_FLIGHT;  // trios in flight (both trio counts, 12 and 8, are multiples of it)
+        uint4 raw[kFlight][3][kRawVecs];
         auto issue = [&](int slot, int t) {
             if (!direct) return;
 #pragma unroll
@@ -1854,15 +1861,24 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
             X[1] = __builtin_amdgcn_alignbit(X[1], X[0], 27);
             X[0] = (X[0] << 5) | b;
         };
-        issue(0, 0);
-        issue(1, 1);
-        for (int t2 = 0; t2 < ntrios; t2 += 2) {
 #pragma unroll
-            for (int slot = 0; slot < 2; ++slot) {
+        for (int slot = 0; slot < kFlight; ++slot) issue(slot, slot);
+        for (int t2 = 0; t2 < ntrios; t2 += kFlight) {
+#pragma unroll
+            for (int slot = 0; slot < kFlight; ++slot) {
                 const int t = t2 + slot;
                 uint32_t R[12];
                 rows_of(slot, t, R);
-                if (t + 2 < ntrios) issue(slot, t + 2);
+                // refills go out in pairs of trios, 96 contiguous bytes back to back: the pieces of a cache line then arrive from one
+                // fetch (a trio at a time, the next piece of a line came a few hundred instructions of seven other wavefronts later)
+                if (RSB_EMIT_BURST) {
+                    if ((slot & 1) && t + kFlight - 1 < ntrios) {
+                        issue(slot - 1, t + kFlight - 1);
+                        issue(slot, t + kFlight);
+                    }
+                } else if (t + kFlight < ntrios) {
+                    issue(slot, t + kFlight);
+                }
                 // demod_2400.c:345-351: sum of mag^2 over rows [0, half_len) (corrected below when the frame starts in an upper half)
 #pragma unroll
                 for (int k = 0; k < 12; ++k) {
