@@ -103,6 +103,23 @@ def test_dcfilter_stream_equals_batched_host_calls(fmt, built):
     assert first_mismatch(want.view(REC_DTYPE), got.view(REC_DTYPE)) is None
 
 
+def test_sc16q11_table_context_streams_one_batch_at_a_time(built):
+    """RSB_FLAG_SC16Q11_TABLE contexts hold one magnitude buffer like --dcfilter ones: the stream collects before it submits.  Bit for
+    bit against the oracle built the same way (convert.c:264-328), Mode A/C on (integer block means of that converter)."""
+    sc = Scenario(7 * BLOCK + 999, seed=43, fmt="SC16Q11", frames_per_sec=3000, modeac_per_sec=300)
+    iq = generate(sc)
+    ch = readsb_amd.Channel(fmt="SC16Q11", fix_bits=1, mode_ac=True, q11_table_bits=8, max_batch_samples=2 * BLOCK)
+    st = readsb_amd.Stream(ch, 2)
+    push_blocks(st, iq)
+    st.close()
+    got = st.messages()
+    assert len(st.parts) >= 4 and ch.stats()["samples_processed"] == sc.n_samples
+    ch.close()
+    want, _ = Oracle(fmt="SC16Q11", nfix=1, modeac=True, q11_table_bits=8).run_stream(iq)
+    assert want.size > 100
+    assert first_mismatch(want, got.view(REC_DTYPE)) is None
+
+
 def _bladerf_frames(iq, block_size, ts0, decimation=1, flags=None):
     """SC16Q11 samples -> the byte stream of bladeRF metadata sub-blocks (sdr_bladerf.c:335-345): magic, timestamp, flags, samples"""
     per = (block_size - 16) // 4
