@@ -1738,6 +1738,9 @@ __global__ __launch_bounds__(kThreads) void k_filter_fill(uint32_t *t0, uint32_t
 #ifndef RSB_EMIT_FLIGHT
 #define RSB_EMIT_FLIGHT 2
 #endif
+#ifndef RSB_AC_BITS_AT_ONCE
+#define RSB_AC_BITS_AT_ONCE 5
+#endif
 #ifndef RSB_EMIT_BURST
 #define RSB_EMIT_BURST 0
 #endif
@@ -2176,17 +2179,35 @@ __device__ __noinline__ void ac_bits(const AcOut a, const uint16_t *m, uint32_t 
     const unsigned signal_threshold = (unsigned)((double)midpoint * 1.41421356237309504880 + 0.5);
     const unsigned noise_threshold = (unsigned)((double)midpoint / 1.41421356237309504880 + 0.5);
 
+    // The 20 bits (:587-608), five at a time: the five windows m[s .. s + 2] are read first -- each as the two aligned dwords that
+    // hold it, one ds_read2_b32 -- and then tested.  (Bit by bit, every step waited for its own three LDS reads: twenty round
+    // trips in a row on the few lanes that get here.)
     unsigned uncertain_bits = 0, noisy_bits = 0, bits = 0, clock = f1_clock;
-    for (int bit = 0; bit < 20; ++bit, clock += 87) {  // (a rolled loop: unrolled it measured 3x slower)
-        const int s = (int)j + (int)(clock / 25 - f1_sample);
-        bits <<= 1;
-        noisy_bits <<= 1;
-        uncertain_bits <<= 1;
-        if (m[s + 2] >= signal_threshold) noisy_bits |= 1;
-        if (m[s] >= signal_threshold || m[s + 1] >= signal_threshold)
-            bits |= 1;
-        else if (m[s] > noise_threshold && m[s + 1] > noise_threshold)
-            uncertain_bits |= 1;
+    constexpr int kBitsAtOnce = RSB_AC_BITS_AT_ONCE;
+    static_assert(20 % kBitsAtOnce == 0, "whole groups");
+    for (int bit0 = 0; bit0 < 20; bit0 += kBitsAtOnce) {
+        uint32_t w0[kBitsAtOnce], w1[kBitsAtOnce], odd[kBitsAtOnce];
+#pragma unroll
+        for (int b = 0; b < kBitsAtOnce; ++b, clock += 87) {
+            const int s = (int)j + (int)(clock / 25 - f1_sample);
+            const uint32_t *w = (const uint32_t *)(m + (s & ~1));  // m = mt + 2 and s & ~1 are even: 4-byte aligned
+            w0[b] = w[0];
+            w1[b] = w[1];
+            odd[b] = ((uint32_t)s & 1u) * 16u;
+        }
+#pragma unroll
+        for (int b = 0; b < kBitsAtOnce; ++b) {
+            const uint32_t pair = __builtin_amdgcn_alignbit(w1[b], w0[b], odd[b]);  // m[s] | m[s + 1] << 16
+            const uint32_t ms = pair & 0xffffu, ms1 = pair >> 16, ms2 = (w1[b] >> odd[b]) & 0xffffu;
+            bits <<= 1;
+            noisy_bits <<= 1;
+            uncertain_bits <<= 1;
+            if (ms2 >= signal_threshold) noisy_bits |= 1;
+            if (ms >= signal_threshold || ms1 >= signal_threshold)
+                bits |= 1;
+            else if (ms > noise_threshold && ms1 > noise_threshold)
+                uncertain_bits |= 1;
+        }
     }
     if ((bits & 0x80020) != 0x80020) return;
     if ((bits & 0x0101B) != 0) return;
