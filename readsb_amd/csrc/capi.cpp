@@ -58,7 +58,7 @@ int setup_device(rsb_ctx *c) {
         return rc;
     }
     if ((rc = upload(c, &c->d_lut, uc8_magnitude_lut(), 65536)) != RSB_OK) return rc;
-    if ((rc = upload(c, &c->d_radial, uc8_radial_lut(), (size_t)kRadialEntries)) != RSB_OK) return rc;
+    if ((rc = upload(c, &c->d_radial, uc8_radial_lut(), (size_t)kRadialTotal)) != RSB_OK) return rc;
     if ((rc = upload(c, &c->d_crc_bytes, CrcTables::byte_table(), 256)) != RSB_OK) return rc;
     if ((rc = upload(c, &c->d_sbs, CrcTables::single_bit_syndromes(), 112)) != RSB_OK) return rc;
     for (int w = 0; w < 2; ++w) {

@@ -156,6 +156,7 @@ struct rsb_ctx {
         a.n = n;
         a.tab.uc8_lut = d_lut;
         a.tab.uc8_radial = d_radial;
+        a.tab.uc8_patch_p1 = rsb::uc8_radial_patch_p1();
         a.tab.crc_bytes = d_crc_bytes;
         a.tab.sbs = d_sbs;
         for (int w = 0; w < 2; ++w) {

@@ -467,7 +467,7 @@ struct SynLds {
 };
 
 struct __attribute__((aligned(16))) ScanShared {
-    uint16_t lut[kRadialEntries];
+    uint16_t lut[kRadialTotal];
     uint32_t coef[10][16];           // [parity of e0 * 5 + trial phase - 4][3 v + dword]: negated tap pairs
     uint32_t bloom[2][kBloomWords];  // one bit per hashed syndrome of the 56- / 112-bit repair table: most lookups end here
     uint32_t gsyn[(12 + 23) * 32];   // per 5-bit group of a 56- / 112-bit frame: XOR of the single-bit syndromes of the set bits
@@ -532,8 +532,8 @@ __device__ __forceinline__ uint4 radial_take(RadialChunk &c, uint32_t &mn) {
 // The radial table into a workgroup's LDS: a plain copy of the table the host built (uc8_radial_lut), 16 bytes per load,
 // biased on the way (bias2 = 0x80008000 for kernels that keep magnitudes biased, 0 otherwise).  Ends with a workgroup barrier.
 __device__ __forceinline__ void load_radial_table(uint16_t *lut, const uint16_t *radial, uint32_t bias2, uint32_t tid, uint32_t nthreads) {
-    static_assert(kRadialEntries % 8 == 0, "whole 16-byte pieces");
-    for (uint32_t i = tid; i < (uint32_t)kRadialEntries / 8; i += nthreads) {
+    static_assert(kRadialTotal % 8 == 0, "whole 16-byte pieces");
+    for (uint32_t i = tid; i < (uint32_t)kRadialTotal / 8; i += nthreads) {
         uint4 v = ((const uint4 *)radial)[i];
         v.x ^= bias2;
         v.y ^= bias2;
@@ -548,7 +548,7 @@ __device__ __forceinline__ void load_radial_table(uint16_t *lut, const uint16_t 
 // takes those samples from the full table in global memory (the kernels that convert a few hundred samples per lane; k_scan
 // checks once per strip instead)
 template <uint32_t BIAS_XOR>
-__device__ __forceinline__ uint4 uc8_chunk_radial_exact(const uint4 x, uint32_t lut_lds, const uint16_t *full) {
+__device__ __forceinline__ uint4 uc8_chunk_radial_exact(const uint4 x, uint32_t lut_lds, const uint32_t patch_p1) {
     using lds_u16 = const __attribute__((address_space(3))) uint16_t;
     const uint32_t X[4] = {x.x, x.y, x.z, x.w};
     typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
@@ -568,10 +568,18 @@ __device__ __forceinline__ uint4 uc8_chunk_radial_exact(const uint4 x, uint32_t 
                       : __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2v, mn), __builtin_bit_cast(ushort2v, o[k])));
     const bool hit = (mn & 0xffffu) == BIAS_XOR || (mn >> 16) == BIAS_XOR;
     if (__builtin_expect(hit, 0)) {
+        // the patch entries behind the table in LDS (kernels.hpp: kRadialPatch), biased like the table.  (From the full table in
+        // global memory this was two dependent round trips to memory for the whole wavefront whenever one lane met a sentinel:
+        // on strong signals a third of the chunks, and most of the time of the kernels that use this function.)
+        auto patch = [&](uint32_t w) -> uint32_t {  // w = the sample's two bytes, I | Q << 8
+            const uint32_t I = w & 0xffu, Q = w >> 8;
+            const uint32_t aidx = I >= 128u ? I - 128u : 127u - I, P = I * (255u - I) + Q * (255u - Q);
+            return *(lds_u16 *)(uintptr_t)(lut_lds + 2u * ((uint32_t)kRadialEntries + (P == patch_p1 ? 128u : 0u) + aidx));
+        };
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if ((o[k] & 0xffffu) == BIAS_XOR) o[k] = (o[k] & 0xffff0000u) | (full[X[k] & 0xffffu] ^ BIAS_XOR);
-            if ((o[k] >> 16) == BIAS_XOR) o[k] = (o[k] & 0xffffu) | ((full[X[k] >> 16] ^ BIAS_XOR) << 16);
+            if ((o[k] & 0xffffu) == BIAS_XOR) o[k] = (o[k] & 0xffff0000u) | patch(X[k] & 0xffffu);
+            if ((o[k] >> 16) == BIAS_XOR) o[k] = (o[k] & 0xffffu) | (patch(X[k] >> 16) << 16);
         }
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
@@ -1736,23 +1744,23 @@ __global__ __launch_bounds__(kThreads) void k_filter_fill(uint32_t *t0, uint32_t
 #define RSB_EMIT_WAVES 8
 #endif
 #ifndef RSB_EMIT_FLIGHT
-#define RSB_EMIT_FLIGHT 2
+#define RSB_EMIT_FLIGHT 4
 #endif
 #ifndef RSB_AC_BITS_AT_ONCE
 #define RSB_AC_BITS_AT_ONCE 5
 #endif
 #ifndef RSB_EMIT_BURST
-#define RSB_EMIT_BURST 0
+#define RSB_EMIT_BURST 1
 #endif
 #ifndef RSB_EMIT_GROUPS
-#define RSB_EMIT_GROUPS 512
+#define RSB_EMIT_GROUPS 256  // one workgroup per CU (180-235 VGPRs: one fits): a second round pays the set-up again, 33 us
 #endif
 constexpr int kEmitGroups = RSB_EMIT_GROUPS;
 constexpr int kEmitWaves = RSB_EMIT_WAVES;   // per workgroup (16 capped the kernel at 128 VGPRs and made it spill); the grid holds kEmitGroups of them
 constexpr int kEmitTrios = 12;       // 3 chunks = 12 rows (24 samples) = 2 groups of five bits per step; 24 groups >= 23
 
 struct __attribute__((aligned(16))) EmitShared {
-    uint16_t lut[kRadialEntries];
+    uint16_t lut[kRadialTotal];
     uint32_t coef[10][16];
     uint32_t gsyn[(12 + 24) * 32];  // + one zero row: the 24th step
     uint32_t rec[kEmitWaves][64 * 14];  // per wavefront: its 64 records, so that they leave as contiguous 16-byte stores
@@ -1770,13 +1778,18 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
         const uint32_t row = i >> 4, e = i & 15;
         sh.coef[row][e] = e < 15 ? coef_entry((int)(row / 5), (int)(row % 5), (int)(e / 3), (int)(e % 3)) : 0u;
     }
+    // the 112 single-bit syndromes go through LDS first (sh.rec is free until the first record): taken from global memory inside
+    // the loop below they were up to five dependent loads per entry, 35 us of set-up per workgroup
+    uint32_t *sbs_lds = &sh.rec[0][0];
+    for (uint32_t i = threadIdx.x; i < 112; i += kT) sbs_lds[i] = a.tab.sbs[i];
+    __syncthreads();
     for (uint32_t i = threadIdx.x; i < (12 + 24) * 32; i += kT) {  // crc.c:59-64, as in the scan kernel
         const bool lng = i >= (uint32_t)kGsynLong;
         const uint32_t e = lng ? i - kGsynLong : i, G = e >> 5, v = e & 31, nbits = lng ? 112 : 56;
         uint32_t x = 0;
         for (uint32_t j = 0; j < 5; ++j) {
             const uint32_t k = 5 * G + j;
-            if (((v >> (4 - j)) & 1) && k < nbits) x ^= a.tab.sbs[k + 112 - nbits];
+            if (((v >> (4 - j)) & 1) && k < nbits) x ^= sbs_lds[k + 112 - nbits];
         }
         sh.gsyn[i] = x;
     }
@@ -1811,11 +1824,13 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
         const uint32_t par = (uint32_t)e0 & 1u;
         const int64_t sd = e0 - (int64_t)par;
         const bool direct = a.iq_aligned && sd >= 0 && sd + 24 * ntrios <= (int64_t)a.n;
-        const uint4_a4 *src = (const uint4_a4 *)((const uint8_t *)a.iq + kBps * sd);
+        // (lanes that cannot read their window directly read the head of the UC8 table instead -- always there, 128 KB -- and
+        // ignore it: behind a branch the compiler cannot count the loads in flight and waits for ALL of them at every use,
+        // refills included, so nothing of the prefetch overlapped anything)
+        const uint4_a4 *src = direct ? (const uint4_a4 *)((const uint8_t *)a.iq + kBps * sd) : (const uint4_a4 *)a.tab.uc8_lut;
         constexpr int kFlight = RSB_EMIT_FLIGHT;  // trios in flight (both trio counts, 12 and 8, are multiples of it)
         uint4 raw[kFlight][3][kRawVecs];
         auto issue = [&](int slot, int t) {
-            if (!direct) return;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -1827,7 +1842,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
                 for (int k = 0; k < 3; ++k) {
                     uint4 o;
                     if constexpr (FMT == kFmtUC8) {
-                        o = uc8_chunk_radial_exact<kBias>(raw[slot][k][0], (uint32_t)(uintptr_t)sh.lut, a.tab.uc8_lut);
+                        o = uc8_chunk_radial_exact<kBias>(raw[slot][k][0], (uint32_t)(uintptr_t)sh.lut, a.tab.uc8_patch_p1);
                     } else if constexpr (FMT == kFmtMag16) {
                         const uint4 x = raw[slot][k][0];
                         o = make_uint4(x.x ^ kBias2, x.y ^ kBias2, x.z ^ kBias2, x.w ^ kBias2);
@@ -1853,7 +1868,8 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
         const uint32_t half_len = nbits * 6 / 5;  // rows of the power sum: signal_len = nbits * 12 / 5 samples (demod_2400.c:342)
         uint32_t X[4] = {0, 0, 0, 0};             // the message as a 128-bit shift register, 5 bits in per group
         uint32_t syn = 0, last_lo = 0, first_lo = 0;
-        uint64_t pw = 0;
+        uint64_t pw = 0;                          // sum of d^2 (see below), turned into the sum of mag^2 after the loop
+        int sum_d = 0;
         uint32_t P[6] = {0, 0, 0, 0, 0, 0};       // rows 6..11 of the previous trio
         auto take_group = [&](uint32_t u, const uint32_t (&D)[8]) {
             uint32_t b = slice_group(D, c);
@@ -1874,22 +1890,38 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
                 rows_of(slot, t, R);
                 // refills go out in pairs of trios, 96 contiguous bytes back to back: the pieces of a cache line then arrive from one
                 // fetch (a trio at a time, the next piece of a line came a few hundred instructions of seven other wavefronts later)
+                // (the refill is unconditional -- past the frame's end it reads the last trio again and nobody uses it: after a
+                // conditional load the compiler no longer knows how many loads are in flight and waits for all of them)
                 if (RSB_EMIT_BURST) {
-                    if ((slot & 1) && t + kFlight - 1 < ntrios) {
-                        issue(slot - 1, t + kFlight - 1);
-                        issue(slot, t + kFlight);
+                    if (slot & 1) {
+                        issue(slot - 1, min(t + kFlight - 1, ntrios - 1));
+                        issue(slot, min(t + kFlight, ntrios - 1));
                     }
-                } else if (t + kFlight < ntrios) {
-                    issue(slot, t + kFlight);
+                } else {
+                    issue(slot, min(t + kFlight, ntrios - 1));
                 }
-                // demod_2400.c:345-351: sum of mag^2 over rows [0, half_len) (corrected below when the frame starts in an upper half)
+                // demod_2400.c:345-351: sum of mag^2 over rows [0, half_len) (corrected below when the frame starts in an upper half).
+                // On the biased pairs d = mag - 32768: sum mag^2 = sum d^2 + 65536 sum d + 2^30 n, both sums one v_dot2_i32_i16
+                // per row (two squares are at most 2^31: the dword is read as unsigned).  half_len is 67 (56 bits) or 134 rows:
+                // trios 0..4 lie inside for every lane; from trio 5 on a lane masks the rows it does not count.
+                if (t < 5) {  // wave-uniform
 #pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    const uint32_t x = R[k] ^ kBias2, row = 12u * (uint32_t)t + k;
-                    const uint64_t lo = x & 0xffffu, hi = x >> 16;
-                    if (row < half_len) pw += lo * lo + hi * hi;
-                    if (row == half_len) last_lo = x & 0xffffu;
+                    for (int k = 0; k < 12; ++k) {
+                        pw += (uint32_t)sdot2_first(R[k], R[k]);
+                        sum_d = sdot2(R[k], 0x00010001u, sum_d);
+                    }
+                } else {
+                    const int rows_in = (int)half_len - 12 * t;  // rows of this trio inside the sum (<= 0: none, >= 12: all)
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) {
+                        const uint32_t x = k < rows_in ? R[k] : 0u;  // d = 0 adds nothing to either sum
+                        pw += (uint32_t)sdot2_first(x, x);
+                        sum_d = sdot2(x, 0x00010001u, sum_d);
+                    }
                 }
+                // row half_len (the frame's last half sample when it starts in an upper half): row 67 = trio 5, row 7; row 134 = trio 11, row 2
+                if (t == 5 && !lng) last_lo = (R[7] ^ kBias2) & 0xffffu;
+                if (t == 11 && lng) last_lo = (R[2] ^ kBias2) & 0xffffu;
                 if (t == 0) first_lo = (R[0] ^ kBias2) & 0xffffu;
                 if (t > 0) {  // group 2t - 1: rows 12t - 6 .. 12t + 1
                     const uint32_t D[8] = {P[0], P[1], P[2], P[3], P[4], P[5], R[0], R[1]};
@@ -1912,6 +1944,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
         }
         uint32_t w[4] = {(X[3] << 8) | (X[2] >> 24), (X[2] << 8) | (X[1] >> 24), (X[1] << 8) | (X[0] >> 24), X[0] << 8};
         const uint32_t df = w[0] >> 27;
+        pw = (uint64_t)((int64_t)pw + 65536ll * (int64_t)sum_d + ((int64_t)(2u * half_len) << 30));  // sum of mag^2 over 2 half_len samples
         if (par) pw += (uint64_t)last_lo * last_lo - (uint64_t)first_lo * first_lo;  // starts in the upper half of row 0, ends in the lower half of row half_len
         const uint32_t signal_len = nbits * 12 / 5;
 
@@ -2123,9 +2156,9 @@ constexpr int kAcChunks = (kAcTile + 74 + 7) / 8;        // 8-sample chunks per 
 static_assert(kBlock % kAcTile == 0 && kTrailing % 8 == 6, "tiles start 328 samples into 16-byte aligned IQ");
 
 template <int FMT>
-__device__ __forceinline__ uint4 ac_chunk(const void *iq, int64_t chunk, const uint16_t *lut, const uint16_t *full) {  // 8 samples from iq index 8 * chunk -> 8 magnitudes
+__device__ __forceinline__ uint4 ac_chunk(const void *iq, int64_t chunk, const uint16_t *lut, const uint32_t patch_p1) {  // 8 samples from iq index 8 * chunk -> 8 magnitudes
     if constexpr (FMT == kFmtUC8) {
-        return uc8_chunk_radial_exact<0u>(((const uint4 *)iq)[chunk], (uint32_t)(uintptr_t)lut, full);
+        return uc8_chunk_radial_exact<0u>(((const uint4 *)iq)[chunk], (uint32_t)(uintptr_t)lut, patch_p1);
     } else if constexpr (FMT == kFmtMag16) {
         return ((const uint4 *)iq)[chunk];
     } else {
@@ -2153,7 +2186,7 @@ __device__ __forceinline__ unsigned ac_f2_clock(const uint16_t *m, int j, unsign
 }
 
 struct __attribute__((aligned(16))) AcShared {
-    uint16_t lut[kRadialEntries];
+    uint16_t lut[kRadialTotal];
     uint16_t mt[8 * kAcChunks];
     uint16_t q1[kAcQ1], q2[kAcQ2];
     uint64_t red[2][kAcThreads / 64];
@@ -2279,13 +2312,13 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
 #pragma unroll
                     for (int k = 0; k < kBatch; ++k) {
                         if constexpr (FMT == kFmtUC8)
-                            take8(uc8_chunk_radial_exact<0u>(raw[k], (uint32_t)(uintptr_t)lut, a.tab.uc8_lut));
+                            take8(uc8_chunk_radial_exact<0u>(raw[k], (uint32_t)(uintptr_t)lut, a.tab.uc8_patch_p1));
                         else
                             take8(raw[k]);
                     }
                 }
             } else {
-                for (uint32_t c = tid; c < nch; c += kAcThreads) take8(ac_chunk<FMT>(a.iq, (int64_t)(blk_start / 8 + c), lut, a.tab.uc8_lut));
+                for (uint32_t c = tid; c < nch; c += kAcThreads) take8(ac_chunk<FMT>(a.iq, (int64_t)(blk_start / 8 + c), lut, a.tab.uc8_patch_p1));
             }
             done = nch * 8;
         }
@@ -2344,12 +2377,12 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
                     const uint32_t c = tid + (uint32_t)k * kAcThreads;
                     if (c >= (uint32_t)kAcChunks) break;
                     if constexpr (FMT == kFmtUC8)
-                        ((uint4 *)mt)[c] = uc8_chunk_radial_exact<0u>(raw[k], (uint32_t)(uintptr_t)lut, a.tab.uc8_lut);
+                        ((uint4 *)mt)[c] = uc8_chunk_radial_exact<0u>(raw[k], (uint32_t)(uintptr_t)lut, a.tab.uc8_patch_p1);
                     else
                         ((uint4 *)mt)[c] = raw[k];
                 }
             } else {
-                for (uint32_t c = tid; c < (uint32_t)kAcChunks; c += kAcThreads) ((uint4 *)mt)[c] = ac_chunk<FMT>(a.iq, q0 / 8 + c, lut, a.tab.uc8_lut);
+                for (uint32_t c = tid; c < (uint32_t)kAcChunks; c += kAcThreads) ((uint4 *)mt)[c] = ac_chunk<FMT>(a.iq, q0 / 8 + c, lut, a.tab.uc8_patch_p1);
             }
         } else {  // the batch's first tile (carry), its last ones (end of the stream), unaligned input
             for (uint32_t i = tid; i < 8u * kAcChunks; i += kAcThreads) mt[i] = (uint16_t)stream_mag<FMT>(a, q0 + (int64_t)kTrailing + i);

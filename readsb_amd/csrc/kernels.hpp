@@ -26,6 +26,9 @@ constexpr int kScanWavesPerGroup = RSB_SCAN_WAVES;
 
 // UC8 magnitudes by radial index P = I (255 - I) + Q (255 - Q) (even, 0 .. 32512): entry P / 2; padded to a multiple of 8 entries
 constexpr int kRadialEntries = 16264;
+// behind the radial entries: the magnitudes of the byte pairs the radial table cannot hold (two values of P, 'classes'), by
+// a = |2 I - 255| (index (a - 1) / 2): [class][128].  modes_host.cpp: uc8_radial_lut / uc8_radial_patch_p1
+constexpr int kRadialPatch = 256, kRadialTotal = kRadialEntries + kRadialPatch;
 
 // device counters (one uint32 each)
 enum : int {
@@ -55,7 +58,8 @@ enum : int {
 
 struct DeviceTables {      // read-only, built once per context
     const uint16_t *uc8_lut;       // 65536 x u16
-    const uint16_t *uc8_radial;    // kRadialEntries x u16: the same magnitudes by radial index (modes_host.cpp: uc8_radial_lut)
+    const uint16_t *uc8_radial;    // kRadialTotal x u16: the same magnitudes by radial index + the patch entries (modes_host.cpp: uc8_radial_lut)
+    uint32_t uc8_patch_p1;         // the P = I (255 - I) + Q (255 - Q) of patch class 1 (any other sentinel entry is class 0)
     const uint32_t *crc_bytes;     // 256 x u32
     const uint32_t *sbs;           // 112 x u32: syndrome of each single set bit of a 112-bit frame (crc.c:40)
     const uint32_t *syn_keys[2];   // [0] = 56-bit frames, [1] = 112-bit frames

@@ -327,6 +327,8 @@ int decode_crc_part(const CrcTables &crc, IcaoFilter &filter, rsb_message &m, ui
 
 // =============================================================================== UC8 LUT
 
+static uint32_t radial_p1 = 0xffffffffu;  // P of patch class 1 (set with the table)
+
 const uint16_t *uc8_radial_lut() {
     // convert.c:35-61 tabulates a function of (2 I - 255)^2 + (2 Q - 255)^2 = 130050 - 4 P, so P / 2 indexes the magnitudes --
     // except where the reference's float rounding gives byte pairs with one P two different values (magnitudes 60465 / 60466 and
@@ -351,8 +353,38 @@ const uint16_t *uc8_radial_lut() {
             }
         for (int k = 0; k < rsb::kRadialEntries; ++k)
             if (state[k] != 1) rad[k] = 0;
+        // The byte pairs of a conflicting entry lie on one circle a^2 + b^2 = 130050 - 4 P, a = |2 I - 255|, b = |2 Q - 255|, and the
+        // table value depends on the unordered pair {a, b} only (the squares are equal for +-a, the sum commutes): a alone picks
+        // it.  Two such P exist; the kernels patch from these 2 x 128 entries in LDS instead of the full table in global memory.
+        std::vector<int> classes;
+        for (int k = 0; k < rsb::kRadialEntries; ++k)
+            if (state[k] == 2) classes.push_back(k);
+        if (classes.size() > 2) {
+            std::fprintf(stderr, "readsb_amd: UC8 table: %zu radial entries with two magnitudes (2 provided for)\n", classes.size());
+            std::abort();
+        }
+        rad.resize(rsb::kRadialTotal, 0);
+        radial_p1 = classes.size() == 2 ? 2u * (uint32_t)classes[1] : 0xffffffffu;
+        for (int q = 0; q < 256; ++q)
+            for (int i = 0; i < 256; ++i) {
+                const int k = (i * (255 - i) + q * (255 - q)) >> 1;
+                if (state[k] != 2) continue;
+                const int cls = (classes.size() == 2 && k == classes[1]) ? 1 : 0, aidx = i >= 128 ? i - 128 : 127 - i;
+                uint16_t &e = rad[rsb::kRadialEntries + 128 * cls + aidx];
+                const uint16_t v = full[(q << 8) | i];
+                if (e != 0 && e != v) {
+                    std::fprintf(stderr, "readsb_amd: UC8 table: |2 I - 255| does not determine the magnitude on circle %d\n", 2 * k);
+                    std::abort();
+                }
+                e = v;
+            }
     });
     return rad.data();
+}
+
+uint32_t uc8_radial_patch_p1() {
+    (void)uc8_radial_lut();
+    return radial_p1;
 }
 
 const uint16_t *uc8_magnitude_lut() {

@@ -131,7 +131,8 @@ int decode_crc_part(const CrcTables &crc, IcaoFilter &filter, rsb_message &m, ui
 // UC8 magnitude table, indexed by the little-endian 16-bit sample word (convert.c:35-61)
 const uint16_t *uc8_magnitude_lut();
 // the same magnitudes indexed by P / 2, P = I (255 - I) + Q (255 - Q); 0 where byte pairs with one P disagree (48 pairs, two entries)
-const uint16_t *uc8_radial_lut();
+const uint16_t *uc8_radial_lut();       // kRadialTotal entries: radial table + patch entries
+uint32_t uc8_radial_patch_p1();         // DeviceTables::uc8_patch_p1
 
 // ---- replay ---------------------------------------------------------------------------------------
 
