@@ -462,6 +462,10 @@ void rsb_destroy(rsb_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->copy_in_flight && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->h_addr_upload) (void)hipHostFree(c->h_addr_upload);
+    if (c->h_many_args) (void)hipHostFree(c->h_many_args);
+    if (c->d_many_args) (void)hipFree(c->d_many_args);
+    for (hipEvent_t ev : c->many_args_read)
+        if (ev) (void)hipEventDestroy(ev);
     if (c->addr_upload_done) (void)hipEventDestroy(c->addr_upload_done);
     void *ptrs[] = {c->d_lut, c->d_radial, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
                     c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
@@ -622,11 +626,26 @@ int rsb_filter_export(rsb_ctx *c, uint32_t *out, size_t cap, size_t *n_out) {
     return RSB_OK;
 }
 
-static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
+// a batch onto the caller's stream in three parts, so that rsb_submit_many can put ONE scan launch between the first and the last
+// part of all its channels
+static int enqueue_before_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, hipStream_t s, bool record_start = true) {
     HIP_TRY(c, hipMemsetAsync(b.d_counters, 0, kCntAlloc * sizeof(uint32_t), s));
     HIP_TRY(c, hipMemsetAsync(b.d_region_counts, 0, (size_t)a.n_regions * sizeof(uint32_t), s));
-    HIP_TRY(c, hipEventRecord(b.ev[0], s));
+    b.scan_share = 1.0f;
+    if (record_start) HIP_TRY(c, hipEventRecord(b.ev[0], s));
+    return RSB_OK;
+}
+
+static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s);
+
+static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
+    int rc = enqueue_before_scan(c, b, a, s);
+    if (rc != RSB_OK) return rc;
     if (c->run_modes) HIP_TRY(c, launch_scan(a, c->scan_grid, s));
+    return enqueue_after_scan(c, b, a, nsamples, s);
+}
+
+static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
     HIP_TRY(c, hipEventRecord(b.ev[1], s));
     // The prune runs at the head of the batch's replay chain, on the context's own stream (rsb_collect, or collect_ahead while
     // the batch before is being delivered), not here: the caller's stream then carries the scans of successive batches back to
@@ -675,7 +694,7 @@ static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t n
     return RSB_OK;
 }
 
-int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) {
+static int submit_checks(rsb_ctx *c, const void *iq_dev, uint64_t nsamples) {
     if (!c || (!iq_dev && nsamples) || c->block_mode) return RSB_EINVAL;
     if (c->submitted - c->collected >= (unsigned)c->nslots) {
         c->err = c->nslots == 1 ? "rsb_submit: previous batch not collected" : "rsb_submit: four batches already in flight: collect one first";
@@ -689,6 +708,12 @@ int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) 
         c->err = "rsb_submit: nsamples exceeds rsb_config.max_batch_samples";
         return RSB_EINVAL;
     }
+    return RSB_OK;
+}
+
+int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) {
+    const int ok = submit_checks(c, iq_dev, nsamples);
+    if (ok != RSB_OK) return ok;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     rsb_slot &b = c->submit_slot();
     hipStream_t s = (hipStream_t)stream;
@@ -999,6 +1024,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
 
     float ms = 0;
     (void)hipEventElapsedTime(&c->timing.scan_ms, b.ev[0], b.ev[1]);
+    c->timing.scan_ms *= b.scan_share;
     c->timing.prune_ms = 0;
     (void)hipEventElapsedTime(&c->timing.modeac_ms, b.ev[2], b.ev[3]);
     (void)hipEventElapsedTime(&c->timing.total_ms, b.ev[0], b.ev[3]);
@@ -1141,8 +1167,75 @@ int rsb_collect_begin(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     return rc;
 }
 
+// All channels' scans as one launch (k_scan_many): same device and format, plain contexts (the converters of dc_filter and the
+// SC16Q11 table write a context-owned buffer first), every channel distinct, at most one channel per scan workgroup.
+static bool one_scan_launch_possible(rsb_ctx *const *ctx, size_t nch, const uint64_t *nsamples) {
+    if (nch < 2 || std::getenv("RSB_NO_SCAN_MANY")) return false;
+    const rsb_ctx *c0 = ctx[0];
+    if (nch > (size_t)c0->scan_grid) return false;
+    for (size_t i = 0; i < nch; ++i) {
+        const rsb_ctx *c = ctx[i];
+        if (!c || c->cfg.device != c0->cfg.device || c->cfg.input_format != c0->cfg.input_format || c->cfg.dc_filter || c->q11_table_bits ||
+            c->block_mode || !c->run_modes || c->scan_grid != c0->scan_grid)
+            return false;
+        for (size_t k = 0; k < i; ++k)
+            if (ctx[k] == c) return false;
+    }
+    (void)nsamples;
+    return true;
+}
+
 int rsb_submit_many(rsb_ctx *const *ctx, size_t nch, const void *const *iq_dev, const uint64_t *nsamples, void *stream) {
     if (!ctx || !iq_dev || !nsamples) return RSB_EINVAL;
+    if (one_scan_launch_possible(ctx, nch, nsamples)) {
+        for (size_t i = 0; i < nch; ++i) {  // nothing is submitted unless every channel can be
+            const int rc = submit_checks(ctx[i], iq_dev[i], nsamples[i]);
+            if (rc != RSB_OK) return rc;
+        }
+        rsb_ctx *c0 = ctx[0];
+        hipStream_t s = (hipStream_t)stream;
+        HIP_TRY(c0, hipSetDevice(c0->cfg.device));
+        if (nch > c0->many_args_cap) {
+            if (c0->d_many_args) (void)hipFree(c0->d_many_args);
+            if (c0->h_many_args) (void)hipHostFree(c0->h_many_args);
+            c0->d_many_args = nullptr;
+            c0->h_many_args = nullptr;
+            c0->many_args_cap = 0;
+            HIP_TRY(c0, hipMalloc((void **)&c0->d_many_args, nch * sizeof(BatchArgs)));
+            HIP_TRY(c0, hipHostMalloc((void **)&c0->h_many_args, 2 * nch * sizeof(BatchArgs), hipHostMallocDefault));
+            c0->many_args_cap = nch;
+            for (hipEvent_t &ev : c0->many_args_read)
+                if (!ev) HIP_TRY(c0, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        // the staging half used two calls ago: its upload has long run, but the host may be that far ahead of the stream
+        const unsigned half = c0->many_calls++ & 1u;
+        if (c0->many_args_pending[half]) HIP_TRY(c0, hipEventSynchronize(c0->many_args_read[half]));
+        BatchArgs *h = c0->h_many_args + half * c0->many_args_cap;
+        const uint32_t groups = (uint32_t)c0->scan_grid / (uint32_t)nch;  // >= 1: one_scan_launch_possible
+        for (size_t i = 0; i < nch; ++i) {
+            rsb_ctx *c = ctx[i];
+            h[i] = c->batch_args(c->submit_slot(), iq_dev[i], nsamples[i], c->cfg.input_format, nullptr, (int)groups);
+            const int rc = enqueue_before_scan(c, c->submit_slot(), h[i], s, false);
+            if (rc != RSB_OK) return rc;
+        }
+        HIP_TRY(c0, hipMemcpyAsync(c0->d_many_args, h, nch * sizeof(BatchArgs), hipMemcpyHostToDevice, s));
+        HIP_TRY(c0, hipEventRecord(c0->many_args_read[half], s));
+        c0->many_args_pending[half] = true;
+        uint64_t total = 0;
+        for (size_t i = 0; i < nch; ++i) total += nsamples[i];
+        for (size_t i = 0; i < nch; ++i) {  // the one launch's time is shared out by samples (rsb_timing.scan_ms)
+            rsb_slot &b = ctx[i]->submit_slot();
+            b.scan_share = total ? (float)((double)nsamples[i] / (double)total) : 0.0f;
+            HIP_TRY(ctx[i], hipEventRecord(b.ev[0], s));
+        }
+        HIP_TRY(c0, launch_scan_many(c0->cfg.input_format, c0->d_many_args, (uint32_t)nch, groups, s));
+        for (size_t i = 0; i < nch; ++i) {
+            rsb_ctx *c = ctx[i];
+            const int rc = enqueue_after_scan(c, c->submit_slot(), h[i], nsamples[i], s);
+            if (rc != RSB_OK) return rc;
+        }
+        return RSB_OK;
+    }
     for (size_t i = 0; i < nch; ++i) {
         if (!ctx[i]) return RSB_EINVAL;
         const int rc = rsb_submit(ctx[i], iq_dev[i], nsamples[i], stream);

@@ -36,6 +36,7 @@ struct rsb_slot {
     bool chain_count_on_device = false, chain_to_host = false;
     rsb::ReplayArgs chain_r;
     bool pending = false;
+    float scan_share = 1.0f;  // rsb_submit_many: this channel's share of the one scan launch (timing.scan_ms)
     const double *means_on_device = nullptr;  // per-block (mean_level, mean_power) of the pending batch, when taken from float means
     uint64_t pending_n = 0, g0 = 0;   // samples of the batch, its stream position
     hipStream_t pending_stream = nullptr;
@@ -144,9 +145,16 @@ struct rsb_ctx {
     std::vector<uint32_t> h_ac_counts;
     std::vector<uint8_t> h_merge;     // device Mode A/C merge: staging of the tables and records it uploads
     uint8_t *d_merge = nullptr;
+    rsb::BatchArgs *d_many_args = nullptr;  // rsb_submit_many: the channels' scan arguments for the one launch (held by the first channel)
+    rsb::BatchArgs *h_many_args = nullptr;  // pinned, two halves used in turn
+    size_t many_args_cap = 0;
+    hipEvent_t many_args_read[2] = {nullptr, nullptr};
+    bool many_args_pending[2] = {false, false};
+    unsigned many_calls = 0;
     size_t merge_cap = 0;
 
-    rsb::BatchArgs batch_args(const rsb_slot &b, const void *iq, uint64_t n, int fmt, const void *carry = nullptr) const {
+    // grid_limit: the scan workgroups this batch may have (0 = the context's scan_grid; rsb_submit_many gives every channel its share)
+    rsb::BatchArgs batch_args(const rsb_slot &b, const void *iq, uint64_t n, int fmt, const void *carry = nullptr, int grid_limit = 0) const {
         rsb::BatchArgs a;
         std::memset(&a, 0, sizeof(a));
         a.iq = iq;
@@ -170,7 +178,8 @@ struct rsb_ctx {
         {
             // one item region per wavefront that will actually run (launch_scan shrinks the grid for small batches)
             const uint64_t nstrips = (n + 2 + rsb::kScanStrip - 1) / rsb::kScanStrip, need = (nstrips + rsb::kScanWavesPerGroup - 1) / rsb::kScanWavesPerGroup;
-            const uint32_t grid = (uint32_t)(need < (uint64_t)scan_grid ? (need ? need : 1) : (uint64_t)scan_grid);
+            const uint64_t most = (uint64_t)(grid_limit > 0 && grid_limit < scan_grid ? grid_limit : scan_grid);
+            const uint32_t grid = (uint32_t)(need < most ? (need ? need : 1) : most);
             a.n_regions = grid * (uint32_t)rsb::kScanWavesPerGroup;
             a.strips_per_wave = (uint32_t)((nstrips + a.n_regions - 1) / a.n_regions);
         }

@@ -769,8 +769,9 @@ __device__ void fill_region_general(const BatchArgs &a, uint16_t *m, int64_t s0,
     }
 }
 
+// The scan of one batch by the workgroups [0, n_regions / 16) given to it; `group` = this workgroup's number among them.
 template <int FMT>
-__global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
+__device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t group) {
     extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
     ScanShared &sh = *reinterpret_cast<ScanShared *>(scan_lds);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform: SGPR
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
     __syncthreads();  // the last workgroup barrier: from here on every wavefront works alone
 
     WaveShared &W = sh.w[wave];
-    const uint32_t gwave = blockIdx.x * kScanWaves + wave;
+    const uint32_t gwave = group * kScanWaves + wave;
     ItemRec *region = a.items + (size_t)gwave * a.item_region;
     uint32_t nitems = 0, gated_total = 0, slow_total = 0, general_strips = 0, fixed_strips = 0, split_strips = 0;  // wave-uniform
     const uint32_t nstrips = (uint32_t)((a.n + kTileShift + kStrip - 1) / kStrip);  // (2^32 strips = 10^13 samples: beyond any HBM)
@@ -1235,6 +1236,24 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
         if (fixed_strips) atomicAdd(&a.counters[kCntFixedStrips], fixed_strips);
         if (split_strips) atomicAdd(&a.counters[kCntSplitStrips], split_strips);
     }
+}
+
+template <int FMT>
+__global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
+    scan_body<FMT>(a, blockIdx.x);
+}
+
+// Many batches (receiver channels) in one launch: batch i has the workgroups [i * groups_per_batch, (i + 1) * groups_per_batch) and its
+// arguments -- built for that many workgroups -- in args[i].  A channel of a few ten Msamples alone gives a wavefront two or three
+// strips and pays the kernel's set-up and ramp for them (33 us per strip against 17 in a long run); side by side the channels'
+// wavefronts each walk a long run of their own channel.
+template <int FMT>
+__global__ __launch_bounds__(kScanThreads) void k_scan_many(const BatchArgs *__restrict__ args, const uint32_t groups_per_batch) {
+    const uint32_t batch = blockIdx.x / groups_per_batch;  // workgroup-uniform: the arguments arrive by scalar loads
+    const BatchArgs a = args[batch];
+    const uint32_t group = blockIdx.x - batch * groups_per_batch;
+    if (a.n == 0 || group * (uint32_t)kScanWaves >= a.n_regions) return;  // (a short batch was given fewer workgroups)
+    scan_body<FMT>(a, group);
 }
 
 // one workgroup per item region (n_regions wave regions + the shared region)
@@ -2897,6 +2916,17 @@ hipError_t launch_scan(const BatchArgs &a, int grid, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanShared));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanThreads), sizeof(ScanShared), s, a);
+        return hipGetLastError();
+    });
+}
+
+hipError_t launch_scan_many(int fmt, const BatchArgs *args_dev, uint32_t nbatches, uint32_t groups_per_batch, hipStream_t s) {
+    if (nbatches == 0 || groups_per_batch == 0) return hipSuccess;
+    return by_format(fmt, [&](auto F) {
+        auto kern = k_scan_many<decltype(F)::value>;
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanShared));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nbatches * groups_per_batch), dim3(kScanThreads), sizeof(ScanShared), s, args_dev, groups_per_batch);
         return hipGetLastError();
     });
 }

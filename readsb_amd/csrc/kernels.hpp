@@ -136,6 +136,8 @@ constexpr uint32_t kNever = 0xffffffffu;
 
 int scan_grid_size(int device);
 hipError_t launch_scan(const BatchArgs &a, int grid, hipStream_t s);
+// nbatches batches of one format in one launch: args_dev[i] built for groups_per_batch workgroups (n_regions = 16 x that), n = 0 allowed
+hipError_t launch_scan_many(int fmt, const BatchArgs *args_dev, uint32_t nbatches, uint32_t groups_per_batch, hipStream_t s);
 hipError_t launch_prune(const BatchArgs &a, hipStream_t s);
 hipError_t launch_prune_ordered(const BatchArgs &a, hipStream_t s);
 // sorts the n_items kept items by (g, phase), derives the ascending list of distinct offsets

@@ -691,6 +691,45 @@ def test_many_channels_in_one_call(built):
         c.close()
 
 
+@pytest.mark.parametrize("fmt,modeac", [("UC8", True), ("SC16", False)])
+def test_one_scan_launch_for_many_channels(fmt, modeac, built):
+    """rsb_submit_many puts the scans of plain channels of one format into ONE launch (k_scan_many: every channel an equal share of the
+    workgroups).  Seven channels of very different lengths -- one shorter than a strip, one empty, one of several blocks with a ragged
+    end -- each against the oracle; a second round continues the streams that have not ended; and a channel set the single launch
+    does not take (one channel twice) still goes through, per channel, with its error."""
+    import torch
+    from readsb_amd.synth import Scenario
+
+    B = 131072
+    first = [3 * B, 2 * B, 1000, 0, B, 5 * B, 2 * B]          # first round: whole blocks continue, the others end their stream
+    second = [B + 777, 0, None, None, 2 * B + 5, 100, B]      # second round (None: the stream has ended)
+    iqs = [generate(Scenario(first[k] + (second[k] or 0), seed=500 + k, fmt=fmt, frames_per_sec=2500 + 300 * k, modeac_per_sec=300 if modeac else 0))
+           if first[k] + (second[k] or 0) else np.zeros((0, 2), dtype=np.uint8 if fmt == "UC8" else "<i2") for k in range(7)]
+    bps = 2 if fmt == "UC8" else 4
+    devs = [torch.from_numpy(np.ascontiguousarray(x)).cuda() if x.shape[0] else torch.zeros(16, dtype=torch.uint8, device="cuda") for x in iqs]
+    want = [Oracle(fmt=fmt, nfix=1, modeac=modeac).run_stream(x)[0] if x.shape[0] else np.zeros(0, dtype=REC_DTYPE) for x in iqs]
+    chans = [readsb_amd.Channel(fmt=fmt, fix_bits=1, mode_ac=modeac, max_batch_samples=5 * B) for _ in range(7)]
+    outs = [torch.empty((1 << 14) * 56, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE) for _ in range(7)]
+    got = [[] for _ in range(7)]
+    readsb_amd.submit_many(chans, [d.data_ptr() for d in devs], first)
+    for k, part in enumerate(readsb_amd.collect_many(chans, outs)):
+        got[k].append(part.copy())
+    live = [k for k in range(7) if second[k] is not None]
+    readsb_amd.submit_many([chans[k] for k in live], [devs[k].data_ptr() + bps * first[k] for k in live], [second[k] for k in live])
+    for k, part in zip(live, readsb_amd.collect_many([chans[k] for k in live], [outs[k] for k in live])):
+        got[k].append(part.copy())
+    for k in range(7):
+        assert first_mismatch(want[k], np.concatenate(got[k]).view(REC_DTYPE)) is None, k
+    assert sum(w.size for w in want) > 1500
+    # a channel that has ended its stream: nothing of the call is submitted (the single launch checks every channel first)
+    with pytest.raises(readsb_amd.RsbError):
+        readsb_amd.submit_many([chans[0], chans[2]], [devs[0].data_ptr(), devs[2].data_ptr()], [B, B])
+    with pytest.raises(readsb_amd.RsbError):
+        chans[0].collect(cap=16)  # nothing pending on the channel that could have been
+    for c in chans:
+        c.close()
+
+
 def Scenario_for(k):
     from readsb_amd.synth import Scenario
 
