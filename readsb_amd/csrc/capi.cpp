@@ -87,6 +87,7 @@ int setup_device(rsb_ctx *c) {
     c->scan_grid = scan_grid_size(c->cfg.device);
     if (const char *e = std::getenv("RSB_STAGE_LIMIT")) c->stage_limit = std::atoi(e);  // ablation timing only
     if (const char *e = std::getenv("RSB_ABL")) c->debug_flags = std::atoi(e);
+    if (const char *e = std::getenv("RSB_SUMMARY_FROM")) c->summary_from = std::strtoull(e, nullptr, 10);  // tests: 0 = always
     if (const char *e = std::getenv("RSB_FORCE_SORT")) c->force_sort = std::atoi(e) != 0;  // A/B and tests: the atomic prune + radix sort
     if (const char *e = std::getenv("RSB_SCAN_GRID")) c->scan_grid = std::atoi(e);
     if (c->cfg.scan_workgroups && (int)c->cfg.scan_workgroups < c->scan_grid) c->scan_grid = (int)c->cfg.scan_workgroups;
@@ -119,6 +120,7 @@ int setup_device(rsb_ctx *c) {
     HIP_TRY(c, hipMalloc((void **)&c->d_surv_g, (size_t)c->surv_item_cap * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_surv, (size_t)c->surv_cap * sizeof(Survivor)));
     HIP_TRY(c, hipMalloc((void **)&c->d_bitmap, (1u << 24) / 8));
+    HIP_TRY(c, hipMalloc((void **)&c->d_summary, kSummaryWords * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_dc_state, sizeof(double2)));
     HIP_TRY(c, hipMemset(c->d_dc_state, 0, sizeof(double2)));
     if (c->cfg.dc_filter || c->q11_table_bits) HIP_TRY(c, hipMalloc((void **)&c->d_magbuf, (size_t)nmax * sizeof(uint16_t) + 16));
@@ -468,7 +470,7 @@ void rsb_destroy(rsb_ctx *c) {
         if (ev) (void)hipEventDestroy(ev);
     if (c->addr_upload_done) (void)hipEventDestroy(c->addr_upload_done);
     void *ptrs[] = {c->d_lut, c->d_radial, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
-                    c->d_bitmap, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
+                    c->d_bitmap, c->d_summary, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
                     c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge};
     for (rsb_slot &b : c->slots) {
         void *sp[] = {b.d_out, b.d_blk_counts, b.d_blk_start, b.d_blk_base, b.d_new_adders, b.d_items, b.d_region_counts, b.d_region_kept, b.d_region_masks, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};

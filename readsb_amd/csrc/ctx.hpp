@@ -145,6 +145,8 @@ struct rsb_ctx {
     std::vector<uint32_t> h_ac_counts;
     std::vector<uint8_t> h_merge;     // device Mode A/C merge: staging of the tables and records it uploads
     uint8_t *d_merge = nullptr;
+    uint32_t *d_summary = nullptr;          // hashed summary of d_bitmap for the ordered prune of large batches (kernels.hip: k_prune_summary)
+    uint64_t summary_from = 1ull << 27;     // samples: below, two more launches cost more than the bitmap reads they save (RSB_SUMMARY_FROM: tests)
     rsb::BatchArgs *d_many_args = nullptr;  // rsb_submit_many: the channels' scan arguments for the one launch (held by the first channel)
     rsb::BatchArgs *h_many_args = nullptr;  // pinned, two halves used in turn
     size_t many_args_cap = 0;
@@ -200,6 +202,7 @@ struct rsb_ctx {
         a.ac = b.d_ac;
         a.ac_cap = ac_cap;
         a.adder_bitmap = d_bitmap;
+        a.adder_summary = (n >= summary_from && !exact_stats) ? d_summary : nullptr;  // (keep_all batches ask nothing)
         a.counters = b.d_counters;
         a.block_sums = b.d_block_sums;
         a.block_means = nullptr;

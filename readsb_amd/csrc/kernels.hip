@@ -1323,6 +1323,25 @@ __global__ __launch_bounds__(kThreads) void k_prune(const BatchArgs a) {
 // ---- the prune as an ordered compaction.  The scan leaves every wavefront's items sorted by (offset, phase) and the regions in
 // stream order (contiguous strip ranges), so the kept items only have to be packed region after region: count per region,
 // exclusive sum over the regions, write.  No atomics on shared counters and no sort afterwards.  One wavefront per region.
+// The ordered prune asks the 2 MiB adder bitmap about every item, 13 M random 4-byte reads per Gsample, each of which pulls a
+// whole cache line into L1 (1.7 GB: what k_prune_count's 70 us were).  A few hundred to a few thousand bits are set.  So, for a
+// large batch, a 4 KB hashed summary of the bitmap is rebuilt in front of the prune (the bitmap is final then: every scan of the
+// batch has run, the caller's additions are in), every workgroup copies it into LDS, and only the items whose summary bit is set
+// -- the members and a few per cent of the others -- go to the bitmap.
+__device__ __forceinline__ uint32_t summary_bit(uint32_t v) { return (v ^ (v >> 9)) & (32u * kSummaryWords - 1u); }
+
+__global__ __launch_bounds__(kThreads) void k_prune_summary(const uint32_t *bitmap, uint32_t *summary) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;  // one 16-byte piece of the bitmap per thread
+    const uint4 w = ((const uint4 *)bitmap)[i];
+    const uint32_t W[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (uint32_t x = W[k]; x; x &= x - 1) {
+            const uint32_t h = summary_bit(((4u * i + (uint32_t)k) << 5) | (uint32_t)__builtin_ctz(x));
+            atomicOr(&summary[h >> 5], 1u << (h & 31));
+        }
+}
+
 __device__ __forceinline__ bool prune_keeps(const BatchArgs &a, const ItemRec &rec) {
     const uint32_t combo = item_combo(rec.info), v = item_value(rec.info);
     if (a.keep_all != 0 || combo == kComboMarker || !combo_needs_member(combo)) return true;
@@ -1336,6 +1355,13 @@ constexpr int kPruneUnroll = 4;
 
 __global__ __launch_bounds__(kThreads) void k_prune_count(const BatchArgs a) {
     __shared__ uint32_t wave_kept[kThreads / 64];
+    __shared__ __attribute__((aligned(16))) uint32_t summary[kSummaryWords];
+    static_assert(kSummaryWords == 4 * kThreads, "one 16-byte piece per thread");
+    const bool summarised = a.adder_summary != nullptr;  // uniform over the grid
+    if (summarised) {
+        ((uint4 *)summary)[threadIdx.x] = ((const uint4 *)a.adder_summary)[threadIdx.x];
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = blockIdx.x;
     uint32_t n = a.region_counts[r];
     if (n > a.item_region) {
@@ -1356,7 +1382,15 @@ __global__ __launch_bounds__(kThreads) void k_prune_count(const BatchArgs a) {
 #pragma unroll
         for (int u = 0; u < kPruneUnroll; ++u) {
             const uint32_t i = (c0 + u) * 64 + lane;
-            const uint64_t km = __ballot(i < n && prune_keeps(a, rec[u]));
+            bool keep;
+            if (summarised) {
+                const uint32_t combo = item_combo(rec[u].info), v = item_value(rec[u].info), h = summary_bit(v);
+                keep = combo == kComboMarker || !combo_needs_member(combo);
+                if (!keep && ((summary[h >> 5] >> (h & 31)) & 1u)) keep = ((a.adder_bitmap[v >> 5] >> (v & 31)) & 1u) != 0;
+            } else {
+                keep = prune_keeps(a, rec[u]);
+            }
+            const uint64_t km = __ballot(i < n && keep);
             if (lane == 0 && c0 + u < nchunks) masks[c0 + u] = km;
             kept += (uint32_t)__popcll(km);
         }
@@ -2941,6 +2975,11 @@ hipError_t launch_prune(const BatchArgs &a, hipStream_t s) {
 // per-thread paths (counters[kCntItems] == 0: the shared region is empty) and no marker items were asked for.
 hipError_t launch_prune_ordered(const BatchArgs &a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
+    if (a.adder_summary) {
+        const hipError_t e = hipMemsetAsync(a.adder_summary, 0, kSummaryWords * sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_prune_summary, dim3((1u << 24) / 32 / 4 / kThreads), dim3(kThreads), 0, s, a.adder_bitmap, a.adder_summary);
+    }
     hipLaunchKernelGGL(k_prune_count, dim3(a.n_regions), dim3(kThreads), 0, s, a);
     hipLaunchKernelGGL(k_prune_offsets, dim3(1), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(k_prune_write, dim3(a.n_regions), dim3(kThreads), 0, s, a);

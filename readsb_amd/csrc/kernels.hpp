@@ -25,6 +25,7 @@ constexpr int kScanStrip = 512 * kScanPasses - 304;          // ... of which the
 constexpr int kScanWavesPerGroup = RSB_SCAN_WAVES;
 
 // UC8 magnitudes by radial index P = I (255 - I) + Q (255 - Q) (even, 0 .. 32512): entry P / 2; padded to a multiple of 8 entries
+constexpr int kSummaryWords = 1024;  // 2^15 bits
 constexpr int kRadialEntries = 16264;
 // behind the radial entries: the magnitudes of the byte pairs the radial table cannot hold (two values of P, 'classes'), by
 // a = |2 I - 255| (index (a - 1) / 2): [class][128].  modes_host.cpp: uc8_radial_lut / uc8_radial_patch_p1
@@ -95,6 +96,7 @@ struct BatchArgs {
     AcCand *ac;
     uint32_t ac_cap;
     uint32_t *adder_bitmap;  // 2^24 bits: superset of every address the filter can hold
+    uint32_t *adder_summary; // kSummaryWords x u32 or null: a hashed summary of the bitmap, rebuilt in front of the ordered prune of a large batch
     uint32_t *counters;
     uint64_t *block_sums;    // per 131072-block: sum(mag), sum(mag^2) over its new samples
     const double *block_means; // or, when the caller already has them (struct mag_buf): mean_level, mean_power per block

@@ -178,6 +178,29 @@ def test_two_batches_in_flight(name, built):
         ch.close()
 
 
+@pytest.mark.parametrize("name", ["mixed_fix1", "dense_fix2_ac", "cfg1_df11_df17"])
+def test_prune_through_the_bitmap_summary(name, built, monkeypatch):
+    """Large batches (>= 2^27 samples) put a 4 KB hashed summary of the adder bitmap in front of the ordered prune (k_prune_summary):
+    forced here for small ones, with addresses put into the filter beforehand (members the scan itself never saw), in two batches
+    (the summary is rebuilt for each) -- against the oracle with the same filter."""
+    monkeypatch.setenv("RSB_SUMMARY_FROM", "0")
+    sc, kw = SCENARIOS[name]
+    iq = generate(sc)
+    cold, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
+    pre = sorted(set(int(a) for a in cold["addr"]))[:64] + _addresses(300, 77)
+    orc = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"])
+    for a in pre:
+        orc.filter_add(a)
+    want, _ = orc.run_stream(iq, reset=False)
+    assert len(want) >= len(cold)
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=8 * 131072)
+    ch.filter_add_many(pre)
+    got = ch.process_stream_host(iq, 8)
+    assert first_mismatch(want, got.view(REC_DTYPE)) is None
+    assert ch.stats()["sort_fallbacks"] == 0  # the ordered prune is the one that ran
+    ch.close()
+
+
 def test_prefilled_filter(built):
     """--show-only style start-up adds (readsb.c:249-250) are seen by the device replay."""
     sc, kw = SCENARIOS["mixed_fix1"]
