@@ -1065,6 +1065,15 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         if (!on_device && !c->host_replay_only) c->filter_dirty = true;  // the host moved the filter on
     }
     c->timing.replay_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+#ifdef RSB_STAGE_CLOCKS
+    {
+        uint32_t dbg[kCntAlloc];
+        HIP_TRY(c, hipDeviceSynchronize());
+        HIP_TRY(c, hipMemcpy(dbg, b.d_counters, sizeof(dbg), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "emit clocks (ticks/16 summed over waves): set-up + loop %u gather %u trios %u repair %u store %u | iterations %u\n", dbg[kDbgEmitSetup],
+                     dbg[kDbgEmitGather], dbg[kDbgEmitTrios], dbg[kDbgEmitRepair], dbg[kDbgEmitStore], dbg[kDbgEmitIters]);
+    }
+#endif
 
     st.samples_processed += b.pending_n;
     st.gated_offsets += cnt[kCntGated];

@@ -1816,6 +1816,7 @@ struct __attribute__((aligned(16))) EmitShared {
     uint16_t lut[kRadialTotal];
     uint32_t coef[10][16];
     uint32_t gsyn[(12 + 24) * 32];  // + one zero row: the 24th step
+    SynLds syn;                      // --fix / --no-fix: the repair tables (as in the scan kernel)
     uint32_t rec[kEmitWaves][64 * 14];  // per wavefront: its 64 records, so that they leave as contiguous 16-byte stores
 };
 
@@ -1846,8 +1847,26 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
         }
         sh.gsyn[i] = x;
     }
+    // the repair tables of --fix into LDS: from global memory the lookup behind the slicing was two dependent trips to memory
+    // per 64 messages, 31 % of this kernel's time (RSB_STAGE_CLOCKS: 22.7 k of 73 k cycles per iteration)
+    const bool syn_in_lds = syn_tables_fit_lds(a.tab);
+    if (syn_in_lds)
+        for (int which = 0; which < 2; ++which) {
+            if (!a.tab.syn_keys[which]) continue;
+            for (uint32_t i = threadIdx.x; i <= a.tab.syn_mask[which]; i += kT) {
+                sh.syn.keys[(which ? 128u : 0u) + i] = a.tab.syn_keys[which][i];
+                sh.syn.vals[(which ? 128u : 0u) + i] = a.tab.syn_vals[which][i];
+            }
+        }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
+#ifdef RSB_STAGE_CLOCKS
+    uint32_t eclk[5] = {0, 0, 0, 0, 0}, eiters = 0;
+    uint64_t et = __builtin_readcyclecounter();
+#define EMIT_STAMP(k) { const uint64_t t_ = __builtin_readcyclecounter(); eclk[k] += (uint32_t)((t_ - et) >> 4); et = t_; }
+#else
+#define EMIT_STAMP(k)
+#endif
     uint32_t nacc = r.counters[kCntAccepted];
     if (nacc > r.out_cap) nacc = r.out_cap;
     if (r.host_out && nacc > r.host_cap) nacc = r.host_cap;
@@ -1856,6 +1875,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
     constexpr int kBps = 2 * kRawVecs;
     const uint32_t nthreads = gridDim.x * kT;
     for (uint32_t base = (blockIdx.x * kT + threadIdx.x) & ~63u; base < nacc; base += nthreads) {
+        EMIT_STAMP(0)  // (set-up before the first iteration; the loop's own bookkeeping afterwards)
         const uint32_t mi = base + lane;
         const bool valid = mi < nacc;
         uint32_t g = 0, phase = 0, info = kComboDf17 << 27, score = 0;
@@ -1871,6 +1891,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
         const bool lng = !combo_is_short(combo);
         const uint32_t nbits = lng ? 112 : 56;
         const bool any_long = __ballot(lng) != 0;
+        EMIT_STAMP(1)  // the message's item: three dependent gathers
         const int ntrios = any_long ? kEmitTrios : 8;  // wave-uniform and even: 56-bit frames end in group 11 (rows 66..73), their power sum in row 67
         // row 0 = the dword that holds S[g + 19] (an even stream index); par = which half of it
         const int64_t e0 = (int64_t)g + 19 - (int64_t)kTrailing;  // index into iq of the first data sample (may be < 0: the overlap)
@@ -1988,6 +2009,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
                 for (int k = 0; k < 6; ++k) P[k] = R[6 + k];
             }
         }
+        EMIT_STAMP(2)  // windows, conversion, slicing, power
         // the 128-bit register has taken 2 ntrios - 1 groups; as if it had taken 24 (message bit 0 at bit 119)
         for (int u = 2 * ntrios - 1; u < 24; ++u) {
             X[3] = __builtin_amdgcn_alignbit(X[3], X[2], 27);
@@ -2005,7 +2027,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
         uint32_t fix = 0;
         if (valid && combo >= kComboDf11Iid0) {
             const uint32_t sy = (combo <= kComboDf11IidX + 1) ? (syn & 0xffff80u) : syn;
-            if (sy) fix = diagnose(a.tab, lng ? 1 : 0, sy);
+            if (sy) fix = syn_in_lds ? diagnose_lds(sh.syn, a.tab, lng ? 1 : 0, sy) : diagnose(a.tab, lng ? 1 : 0, sy);
             if (fix == 0xffffffffu) fix = 0;  // cannot happen for an item the scan classified; keep the frame as sliced
         }
         const uint32_t nerr = fix & 0xffu;
@@ -2015,6 +2037,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
             for (int k = 0; k < 4; ++k)
                 if ((p >> 5) == (uint32_t)k) w[k] ^= 1u << (31 - (p & 31));
         }
+        EMIT_STAMP(3)  // repair
         if (valid) {
             const uint64_t ts = 5 * (r.g0 + g) + (8 + 56) * 12 + (phase + 4);  // demod_2400.c:320
             const bool parity_addr = combo <= kComboCommB;
@@ -2057,6 +2080,10 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
             }
             wave_sync();
         }
+        EMIT_STAMP(4)  // record (level in double) into LDS, records out
+#ifdef RSB_STAGE_CLOCKS
+        ++eiters;
+#endif
         by_errors[0] += (uint32_t)__popcll(__ballot(valid && nerr == 0));
         by_errors[1] += (uint32_t)__popcll(__ballot(valid && nerr == 1));
         by_errors[2] += (uint32_t)__popcll(__ballot(valid && nerr >= 2));
@@ -2064,6 +2091,12 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
     if (lane == 0)
         for (int e = 0; e < 3; ++e)
             if (by_errors[e]) atomicAdd(&a.counters[kCntAccE0 + e], by_errors[e]);
+#ifdef RSB_STAGE_CLOCKS
+    if (lane == 0) {
+        for (int k = 0; k < 5; ++k) atomicAdd(&a.counters[kDbgEmitSetup + k], eclk[k]);
+        atomicAdd(&a.counters[kDbgEmitIters], eiters);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

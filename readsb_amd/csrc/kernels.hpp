@@ -54,7 +54,9 @@ enum : int {
     // debug builds (RSB_STAGE_CLOCKS) and ablation runs only
     kDbgClkConvert = 20, kDbgClkEdge, kDbgClkGate, kDbgClkDf, kDbgClkSlice, kDbgStrips, kDbgGateBatches, kDbgDfBatches, kDbgSliceBatches,
     kDbgEdgeCands, kDbgFrames, kDbgLongFrames,
-    kCntAlloc = 32
+    // k_replay_emit, RSB_STAGE_CLOCKS builds: ticks / 16 summed over wavefronts per stage of an iteration of 64 messages, and the iterations
+    kDbgEmitSetup = 32, kDbgEmitGather, kDbgEmitTrios, kDbgEmitRepair, kDbgEmitStore, kDbgEmitIters,
+    kCntAlloc = 40
 };
 
 struct DeviceTables {      // read-only, built once per context
