@@ -92,6 +92,12 @@ int setup_device(rsb_ctx *c) {
     if (const char *e = std::getenv("RSB_SCAN_GRID")) c->scan_grid = std::atoi(e);
     if (c->cfg.scan_workgroups && (int)c->cfg.scan_workgroups < c->scan_grid) c->scan_grid = (int)c->cfg.scan_workgroups;
     if (c->scan_grid < 1) c->scan_grid = 1;
+    if (const char *e = std::getenv("RSB_CHUNK_STRIPS")) c->chunk_strips_forced = (uint32_t)std::atoi(e);
+    c->chunks_cap = (size_t)((nmax + 2 + kScanStrip - 1) / kScanStrip) + 1;  // chunks of one strip: the most a batch can have
+    if (std::getenv("RSB_WAVE_TIMES")) {  // measurement runs only (tools/wave_times.py)
+        HIP_TRY(c, hipMalloc((void **)&c->d_wave_times, (size_t)c->scan_grid * kScanWavesPerGroup * 4 * sizeof(uint64_t)));
+        HIP_TRY(c, hipMemset(c->d_wave_times, 0, (size_t)c->scan_grid * kScanWavesPerGroup * 4 * sizeof(uint64_t)));
+    }
     // --dcfilter (and the SC16Q11 table converter) keeps one magnitude buffer, which the replay of a batch still reads: one batch in flight there
     c->q11_table_bits = (int)RSB_FLAG_SC16Q11_TABLE_BITS_OF(c->cfg.flags);
     c->nslots = (c->cfg.dc_filter || c->q11_table_bits) ? 1 : rsb_ctx::kMaxSlots;
@@ -101,6 +107,9 @@ int setup_device(rsb_ctx *c) {
         HIP_TRY(c, hipMalloc((void **)&b.d_region_counts, (size_t)c->scan_grid * kScanWavesPerGroup * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void **)&b.d_region_kept, (size_t)c->scan_grid * kScanWavesPerGroup * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void **)&b.d_region_masks, ((size_t)c->item_cap / 64 + (size_t)c->scan_grid * kScanWavesPerGroup) * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc((void **)&b.d_chunk_dir, c->chunks_cap * sizeof(uint2)));
+        HIP_TRY(c, hipMalloc((void **)&b.d_chunk_kept, c->chunks_cap * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&b.d_chunk_group, (c->chunks_cap / 256 + 2) * sizeof(uint32_t)));
         for (int w = 0; w < 2; ++w) {
             HIP_TRY(c, hipMalloc((void **)&b.d_skeys[w], (size_t)c->surv_item_cap * sizeof(uint64_t)));
             HIP_TRY(c, hipMalloc((void **)&b.d_sinfo[w], (size_t)c->surv_item_cap * sizeof(uint32_t)));
@@ -471,9 +480,9 @@ void rsb_destroy(rsb_ctx *c) {
     if (c->addr_upload_done) (void)hipEventDestroy(c->addr_upload_done);
     void *ptrs[] = {c->d_lut, c->d_radial, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
                     c->d_bitmap, c->d_summary, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
-                    c->d_magbuf, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge};
+                    c->d_magbuf, c->d_wave_times, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge};
     for (rsb_slot &b : c->slots) {
-        void *sp[] = {b.d_out, b.d_blk_counts, b.d_blk_start, b.d_blk_base, b.d_new_adders, b.d_items, b.d_region_counts, b.d_region_kept, b.d_region_masks, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
+        void *sp[] = {b.d_out, b.d_blk_counts, b.d_blk_start, b.d_blk_base, b.d_new_adders, b.d_items, b.d_region_counts, b.d_region_kept, b.d_region_masks, b.d_chunk_dir, b.d_chunk_kept, b.d_chunk_group, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
         for (void *p : sp)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : b.ev)
@@ -1082,6 +1091,14 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     st.split_strips += cnt[kCntSplitStrips];
     st.sort_fallbacks = c->sort_fallbacks;
     if (std::getenv("RSB_VERBOSE")) std::fprintf(stderr, "readsb_amd: %u strips converted on the general path, %u patched from the full UC8 table, %u split, %u gated offsets\n", cnt[kCntGeneralStrips], cnt[kCntFixedStrips], cnt[kCntSplitStrips], cnt[kCntGated]);
+    if (c->d_wave_times) {
+        std::vector<uint64_t> wt((size_t)a.n_regions * 4);
+        HIP_TRY(c, hipMemcpy(wt.data(), c->d_wave_times, wt.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen(std::getenv("RSB_WAVE_TIMES"), "wb")) {
+            std::fwrite(wt.data(), sizeof(uint64_t), wt.size(), f);
+            std::fclose(f);
+        }
+    }
     st.live_candidates += cnt[kCntItemsTotal];
     st.survivors += on_device ? cnt[kCntAccepted] : cnt[kCntSurvivors];
     st.modeac_candidates += cnt[kCntAc];

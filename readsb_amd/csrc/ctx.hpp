@@ -17,6 +17,8 @@ struct rsb_slot {
     uint32_t *d_region_counts = nullptr;
     uint32_t *d_region_kept = nullptr;
     uint64_t *d_region_masks = nullptr;
+    uint2 *d_chunk_dir = nullptr;
+    uint32_t *d_chunk_kept = nullptr, *d_chunk_group = nullptr;
     bool pruned = false;              // the filter-superset prune of the pending batch has been enqueued
     bool pruned_in_order = false;     // ... as launch_prune_ordered: its kept items need no sort
     uint64_t *d_skeys[2] = {nullptr, nullptr};
@@ -72,7 +74,10 @@ struct rsb_ctx {
     bool force_sort = false;          // RSB_FORCE_SORT: always the atomic prune + radix sort (A/B runs)
     unsigned sort_fallbacks = 0;      // batches that had to be pruned again with the sort (a scan wavefront overflowed an LDS queue)
     int stage_limit = 99;
+    uint32_t chunk_strips_forced = 0;  // RSB_CHUNK_STRIPS (tuning runs)
+    size_t chunks_cap = 0;
     int debug_flags = 0;
+    uint64_t *d_wave_times = nullptr;  // RSB_WAVE_TIMES=<file>: the scan wavefronts' start / end stamps of the last collected batch go there
     uint32_t *d_bitmap = nullptr;
     size_t nblocks_cap = 0;
     void *d_stage = nullptr;
@@ -183,14 +188,20 @@ struct rsb_ctx {
             const uint64_t most = (uint64_t)(grid_limit > 0 && grid_limit < scan_grid ? grid_limit : scan_grid);
             const uint32_t grid = (uint32_t)(need < most ? (need ? need : 1) : most);
             a.n_regions = grid * (uint32_t)rsb::kScanWavesPerGroup;
-            a.strips_per_wave = (uint32_t)((nstrips + a.n_regions - 1) / a.n_regions);
+            // chunks of two strips once every wavefront has a long run of them (the last chunks bound the imbalance at the end of the
+            // launch: two strips are ~35 us of 1.3 ms per Gsample), single strips for small batches
+            a.chunk_strips = chunk_strips_forced ? chunk_strips_forced : (nstrips / a.n_regions >= 16 ? 2u : 1u);
+            a.n_chunks = (uint32_t)((nstrips + a.chunk_strips - 1) / a.chunk_strips);
         }
         a.shared_cap = item_cap / 16;
-        a.item_region = (item_cap - a.shared_cap) / a.n_regions;
+        a.item_region = (item_cap - a.shared_cap) / a.n_regions / 64 * 64;  // whole keep masks
+        a.chunk_dir = b.d_chunk_dir;
+        a.chunk_kept = b.d_chunk_kept;
+        a.chunk_group = b.d_chunk_group;
         a.region_counts = b.d_region_counts;
         a.region_kept = b.d_region_kept;
         a.region_masks = b.d_region_masks;
-        a.mask_stride = (a.item_region + 63) / 64;
+        a.mask_stride = a.item_region / 64;
         a.surv_item_cap = surv_item_cap;
         for (int w = 0; w < 2; ++w) {
             a.skeys[w] = b.d_skeys[w];
@@ -210,6 +221,7 @@ struct rsb_ctx {
         a.keep_all = exact_stats ? 1 : 0;
         a.stage_limit = stage_limit;
         a.debug_flags = debug_flags;
+        a.wave_times = d_wave_times;
         return a;
     }
 };

@@ -472,6 +472,8 @@ struct __attribute__((aligned(16))) ScanShared {
     uint32_t bloom[2][kBloomWords];  // one bit per hashed syndrome of the 56- / 112-bit repair table: most lookups end here
     uint32_t gsyn[(12 + 23) * 32];   // per 5-bit group of a 56- / 112-bit frame: XOR of the single-bit syndromes of the set bits
     SynLds syn;                      // --fix / --no-fix: the repair tables themselves
+    unsigned long long pool;         // chunk numbers for the workgroup's wavefronts: first chunk of the super-chunk << 32 | chunks taken
+    unsigned long long pad_;
     WaveShared w[kScanWaves];
 };
 static_assert(kPasses >= 2 && kPasses <= 8 && kStrip / 8 > 64 * (kPasses - 1), "bit-sliced bytes hold up to 8 passes; the last pass must hold scan offsets");
@@ -775,6 +777,7 @@ __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t gro
     extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
     ScanShared &sh = *reinterpret_cast<ScanShared *>(scan_lds);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform: SGPR
+    const uint64_t wave_t0 = a.wave_times ? wall_clock64() : 0;
 
     if (FMT == kFmtUC8) load_radial_table(sh.lut, a.tab.uc8_radial, kBias2, tid, kScanThreads);
     for (uint32_t i = tid; i < 2 * kBloomWords; i += kScanThreads) sh.bloom[0][i] = 0;
@@ -808,6 +811,7 @@ __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t gro
             }
         }
     }
+    if (tid == 0) sh.pool = (unsigned long long)(group * (uint32_t)kScanWaves) << 32;
     __syncthreads();  // the last workgroup barrier: from here on every wavefront works alone
 
     WaveShared &W = sh.w[wave];
@@ -852,17 +856,60 @@ __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t gro
             return make_uint4(sc16_pair<FMT>(x0, 0), sc16_pair<FMT>(x0, 1), sc16_pair<FMT>(x1, 0), sc16_pair<FMT>(x1, 1));
         }
     };
-    // Every wavefront takes a CONTIGUOUS run of strips (a.strips_per_wave of them), in ascending order: its item region then is
-    // one sorted run of the batch's items, the regions follow each other in stream order, and the prune that comes next only
-    // has to compact them in place of a global sort.
-    const uint32_t strip_step = 1;
-    const uint64_t first = (uint64_t)gwave * a.strips_per_wave;
-    const uint32_t strip_lo = first < nstrips ? (uint32_t)first : nstrips;
-    const uint32_t strip_hi = a.stage_limit < 1 ? strip_lo  // (ablation: the table set-up alone)
-                                                : (first + a.strips_per_wave < nstrips ? (uint32_t)(first + a.strips_per_wave) : nstrips);
-    if (RSB_PREFETCH_EARLY && strip_lo < strip_hi) prefetch(strip_lo);
+    // The strips are handed out in CHUNKS of a.chunk_strips consecutive strips, to whichever wavefront is free next: traffic is
+    // uneven along a recording (on the benchmark's, equal runs of strips took between 0.88 and 1.58 ms: the average wavefront
+    // was resident for 75 % of the launch, profiles/r3_wave_times_before.json).  A wavefront walks its chunk's strips in ascending
+    // order, so a chunk's items are one sorted run; chunk_dir says where each chunk's run lies, and the ordered prune packs the runs
+    // in chunk order = stream order.  Chunk numbers come from a two-level counter: the workgroup's pool in LDS holds one
+    // super-chunk (kScanWaves chunks); the wavefront that finds it used up takes the next super-chunk number from the batch's
+    // counter in memory (same-address atomics retire at ~0.1 per ns: one per chunk and wavefront would be too many) and refills
+    // the pool.  Every workgroup's first super-chunk is its own number: no atomic before the first strip.
+    const uint32_t n_groups = a.n_regions / (uint32_t)kScanWaves;
+    auto grab_chunk = [&]() -> uint32_t {  // wave-uniform; >= a.n_chunks: nothing is left
+        for (;;) {
+            unsigned long long v = 0;
+            if (lane == 0) v = __hip_atomic_fetch_add(&sh.pool, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+            if (idx < (uint32_t)kScanWaves) return base + idx;
+            if (idx == (uint32_t)kScanWaves) {  // the first to find the pool empty refills it (and takes the new super-chunk's first chunk)
+                uint32_t sc = 0;
+                if (lane == 0) sc = atomicAdd(&a.counters[kCntSuperChunks], 1u);
+                sc = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc) + n_groups;
+                const uint32_t nb = sc < 0x08000000u ? sc * (uint32_t)kScanWaves : 0xffffff00u;  // (past the end: stays past the end)
+                if (lane == 0) __hip_atomic_store(&sh.pool, ((unsigned long long)nb << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return nb;
+            }
+            __builtin_amdgcn_s_sleep(16);  // another wavefront is refilling
+        }
+    };
+    const uint32_t n_chunks = a.stage_limit < 1 ? 0u : a.n_chunks;  // (ablation: the table set-up alone)
+    uint32_t chunk = grab_chunk(), chunk_items0 = 0, strips_taken = 0;
+    uint32_t strip = chunk < n_chunks ? chunk * a.chunk_strips : nstrips;
+    uint32_t chunk_end = strip < nstrips ? min(strip + a.chunk_strips, nstrips) : nstrips;
+    uint32_t next_strip = nstrips, chunk_next = chunk;
+    // closes the chunk when its last strip is done, and steps to the strip chosen at the top of the body
+    auto advance = [&]() {
+        ++strips_taken;
+        if (chunk_next != chunk || next_strip >= nstrips) {
+            const uint32_t cap = a.item_region, lo = min(chunk_items0, cap), hi = min(nitems, cap);
+            if (lane == 0) a.chunk_dir[chunk] = make_uint2(gwave * cap + lo, hi - lo);
+            chunk_items0 = nitems;
+            chunk = chunk_next;
+            chunk_end = next_strip < nstrips ? min(next_strip + a.chunk_strips, nstrips) : nstrips;
+        }
+        strip = next_strip;
+    };
+    if (RSB_PREFETCH_EARLY && strip < nstrips) prefetch(strip);
     DBG_DECL
-    for (uint32_t strip = strip_lo; strip < strip_hi; strip += strip_step) {
+    for (; strip < nstrips; advance()) {
+        // which strip comes next (needed early: its raw IQ is requested while this strip is worked on)
+        if (strip + 1 < chunk_end) {
+            next_strip = strip + 1;
+        } else {
+            chunk_next = grab_chunk();
+            next_strip = chunk_next < n_chunks ? chunk_next * a.chunk_strips : nstrips;
+        }
         const int64_t s0 = (int64_t)((uint64_t)strip * kStrip) - kTileShift;  // S index of m[0]
         if (!RSB_PREFETCH_EARLY) prefetch(strip);
         if (kLatePasses) fetch_passes(strip, kPasses - kLatePasses, kPasses);
@@ -951,7 +998,7 @@ __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t gro
             for (int t = 0; t < kPasses; ++t) take_chunk(t, ((const uint4 *)W.m)[(int)lane + 64 * t]);
         }
         edge_accumulate(prev, from_next_lane(lane == 0 ? 0u : prev.x), acc);  // chunk 511 has no successor: not a scan offset
-        if (RSB_PREFETCH_EARLY && strip + 1 < strip_hi) prefetch(strip + 1);
+        if (RSB_PREFETCH_EARLY && next_strip < nstrips) prefetch(next_strip);
         wave_sync();
         DBG_STAGE(0) DBG_COUNT(0, 1)
         if (a.stage_limit < 2) continue;
@@ -1228,8 +1275,16 @@ __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t gro
         slow_total += slow_strip;
     }
     DBG_FLUSH
+    if (a.wave_times && lane == 0) {
+        uint64_t *wt = a.wave_times + 4 * (size_t)gwave;
+        wt[0] = wave_t0;
+        wt[1] = wall_clock64();
+        wt[2] = ((uint64_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);  // XCC_ID, HW_ID
+        wt[3] = strips_taken;
+    }
     if (lane == 0) {
         a.region_counts[gwave] = nitems;
+        if (nitems > a.item_region) atomicAdd(&a.counters[kCntOverflow], 1u);
         if (gated_total) atomicAdd(&a.counters[kCntGated], gated_total);
         if (slow_total) atomicAdd(&a.counters[kCntSlowPath], slow_total);
         if (general_strips) atomicAdd(&a.counters[kCntGeneralStrips], general_strips);
@@ -1275,6 +1330,7 @@ __global__ __launch_bounds__(kThreads) void k_prune(const BatchArgs a) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     auto keeps = [&](const ItemRec &rec) {
         const uint32_t combo = item_combo(rec.info), v = item_value(rec.info);
+        if (rec.info == kDeadItem) return false;  // padding between the chunks of a region
         if (a.keep_all != 0 || combo == kComboMarker || !combo_needs_member(combo)) return true;
         return ((a.adder_bitmap[v >> 5] >> (v & 31)) & 1u) != 0;
     };
@@ -1285,16 +1341,26 @@ __global__ __launch_bounds__(kThreads) void k_prune(const BatchArgs a) {
     __shared__ uint32_t block_base;
     const uint32_t per_wave = (n + kThreads / 64 - 1) / (kThreads / 64);
     const uint32_t w_lo = min(n, wave * per_wave), w_hi = min(n, w_lo + per_wave);
-    uint32_t mine = 0;
+    __shared__ uint32_t wave_live[kThreads / 64];
+    uint32_t mine = 0, live = 0;
     for (uint32_t base = w_lo; base < w_hi; base += 64) {
         const uint32_t i = base + lane;
-        mine += (uint32_t)__popcll(__ballot(i < w_hi && keeps(items[i])));
+        const ItemRec rec = i < w_hi ? items[i] : ItemRec{0, kDeadItem};
+        mine += (uint32_t)__popcll(__ballot(keeps(rec)));
+        live += (uint32_t)__popcll(__ballot(rec.info != kDeadItem));
     }
-    if (lane == 0) wave_count[wave] = mine;
+    if (lane == 0) {
+        wave_count[wave] = mine;
+        wave_live[wave] = live;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t total = 0;
-        for (uint32_t w = 0; w < kThreads / 64; ++w) total += wave_count[w];
+        n = 0;
+        for (uint32_t w = 0; w < kThreads / 64; ++w) {
+            total += wave_count[w];
+            n += wave_live[w];
+        }
         // kept items (the reservation) and all items (a statistic) in one atomic: same-address atomics are what this kernel waits for
         static_assert(kCntSurvItems % 2 == 0 && kCntItemsTotal == kCntSurvItems + 1, "the two counters form one aligned 64-bit word");
         block_base = n ? (uint32_t)atomicAdd((unsigned long long *)&a.counters[kCntSurvItems], (unsigned long long)total | ((unsigned long long)n << 32)) : 0u;
@@ -1344,6 +1410,7 @@ __global__ __launch_bounds__(kThreads) void k_prune_summary(const uint32_t *bitm
 
 __device__ __forceinline__ bool prune_keeps(const BatchArgs &a, const ItemRec &rec) {
     const uint32_t combo = item_combo(rec.info), v = item_value(rec.info);
+    if (rec.info == kDeadItem) return false;  // padding between the chunks of a region
     if (a.keep_all != 0 || combo == kComboMarker || !combo_needs_member(combo)) return true;
     return ((a.adder_bitmap[v >> 5] >> (v & 31)) & 1u) != 0;
 }
@@ -1385,8 +1452,8 @@ __global__ __launch_bounds__(kThreads) void k_prune_count(const BatchArgs a) {
             bool keep;
             if (summarised) {
                 const uint32_t combo = item_combo(rec[u].info), v = item_value(rec[u].info), h = summary_bit(v);
-                keep = combo == kComboMarker || !combo_needs_member(combo);
-                if (!keep && ((summary[h >> 5] >> (h & 31)) & 1u)) keep = ((a.adder_bitmap[v >> 5] >> (v & 31)) & 1u) != 0;
+                keep = (combo == kComboMarker || !combo_needs_member(combo)) && rec[u].info != kDeadItem;
+                if (!keep && combo_needs_member(combo) && ((summary[h >> 5] >> (h & 31)) & 1u)) keep = ((a.adder_bitmap[v >> 5] >> (v & 31)) & 1u) != 0;
             } else {
                 keep = prune_keeps(a, rec[u]);
             }
@@ -1404,84 +1471,123 @@ __global__ __launch_bounds__(kThreads) void k_prune_count(const BatchArgs a) {
     }
 }
 
-// exclusive sum of the regions' kept counts (at most a few thousand regions: one workgroup); the totals go to the counters
+// The kept items leave in CHUNK order (= stream order; the chunks' runs lie wherever their wavefronts put them).  Per chunk: kept
+// items = the popcounts of its keep masks; exclusive sums in two levels -- within groups of 256 chunks here, over the groups in
+// k_prune_offsets.
+constexpr int kChunkGroup = 256;
+// the keep mask word that holds item slot `slot` (item_region % 64 == 0: region r's words start at r * mask_stride)
+__device__ __forceinline__ const uint64_t *slot_mask_word(const BatchArgs &a, uint32_t slot) { return a.region_masks + (slot >> 6); }
+// the bits of mask word number w (counted from the word that holds the chunk's first slot) that belong to the chunk [first, first + n)
+__device__ __forceinline__ uint64_t chunk_word_bits(uint32_t first, uint32_t n, uint32_t w) {
+    const uint32_t lo = first & 63u, end = lo + n;  // the chunk's slots, counted from its first word's bit 0
+    uint64_t bits = ~0ull;
+    if (w == 0) bits &= ~0ull << lo;
+    if (end < 64u * (w + 1)) bits &= end > 64u * w ? ~0ull >> (64u * (w + 1) - end) : 0ull;
+    return bits;
+}
+
+__global__ __launch_bounds__(kChunkGroup) void k_prune_chunks(const BatchArgs a) {
+    __shared__ uint32_t wave_sum[kChunkGroup / 64], wave_all[kChunkGroup / 64];
+    const uint32_t c = blockIdx.x * kChunkGroup + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t kept = 0, all = 0;
+    if (c < a.n_chunks) {
+        const uint2 d = a.chunk_dir[c];
+        const uint64_t *masks = slot_mask_word(a, d.x);
+        all = d.y;
+        const uint32_t nwords = d.y ? ((d.x & 63u) + d.y + 63u) / 64u : 0u;
+        for (uint32_t w = 0; w < nwords; ++w) kept += (uint32_t)__popcll(masks[w] & chunk_word_bits(d.x, d.y, w));
+    }
+    uint32_t incl = kept, incl_all = all;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64), up_all = (uint32_t)__shfl_up((int)incl_all, off, 64);
+        if ((int)lane >= off) {
+            incl += up;
+            incl_all += up_all;
+        }
+    }
+    if (lane == 63) {
+        wave_sum[wave] = incl;
+        wave_all[wave] = incl_all;
+    }
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_sum[w];
+    if (c < a.n_chunks) a.chunk_kept[c] = before + incl - kept;
+    if (threadIdx.x == kChunkGroup - 1) {
+        uint32_t total_all = 0;
+        for (uint32_t w = 0; w < kChunkGroup / 64; ++w) total_all += wave_all[w];
+        a.chunk_group[blockIdx.x] = before + incl;
+        atomicAdd(&a.counters[kCntItemsTotal], total_all);  // a statistic (one atomic per 256 chunks)
+    }
+}
+
+// exclusive sum over the groups' totals (one workgroup; a Gsample has a few hundred groups); the total goes to the counters
 __global__ __launch_bounds__(1024) void k_prune_offsets(const BatchArgs a) {
     __shared__ uint32_t part[1024];
-    __shared__ uint32_t part_all[1024];
-    const uint32_t t = threadIdx.x, per = (a.n_regions + 1023) / 1024, lo = min(a.n_regions, t * per), hi = min(a.n_regions, lo + per);
-    uint32_t sum = 0, all = 0;
-    for (uint32_t r = lo; r < hi; ++r) {
-        sum += a.region_kept[r];
-        all += min(a.region_counts[r], a.item_region);
-    }
+    const uint32_t ngroups = (a.n_chunks + kChunkGroup - 1) / kChunkGroup;
+    const uint32_t t = threadIdx.x, per = (ngroups + 1023) / 1024, lo = min(ngroups, t * per), hi = min(ngroups, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t r = lo; r < hi; ++r) sum += a.chunk_group[r];
     part[t] = sum;
-    part_all[t] = all;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
-        const uint32_t add = t >= d ? part[t - d] : 0u, add_all = t >= d ? part_all[t - d] : 0u;
+        const uint32_t add = t >= d ? part[t - d] : 0u;
         __syncthreads();
         part[t] += add;
-        part_all[t] += add_all;
         __syncthreads();
     }
     uint32_t run = part[t] - sum;  // exclusive
     for (uint32_t r = lo; r < hi; ++r) {
-        const uint32_t k = a.region_kept[r];
-        a.region_kept[r] = run;
+        const uint32_t k = a.chunk_group[r];
+        a.chunk_group[r] = run;
         run += k;
     }
-    if (t == 1023) {
-        a.counters[kCntSurvItems] = part[1023];
-        a.counters[kCntItemsTotal] = part_all[1023];
-    }
+    if (t == 1023) a.counters[kCntSurvItems] = part[1023];
 }
 
-constexpr int kPruneMaskCap = 4096;  // keep masks of a region held in LDS at a time (= 262144 items)
+// Eight lanes per chunk: its kept items to their places.  Sub-lane l takes keep mask word l of the chunk (a chunk of two strips has
+// two or three), so the words and then the kept items of eight chunks are fetched side by side in a wavefront.
+constexpr int kWriteLanes = 8;
 __global__ __launch_bounds__(kThreads) void k_prune_write(const BatchArgs a) {
-    __shared__ uint32_t before[kPruneMaskCap];  // kept items of the region before chunk c
-    __shared__ uint32_t wave_sum[kThreads / 64];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = blockIdx.x;
-    const uint32_t n = min(a.region_counts[r], a.item_region), nchunks = (n + 63) / 64;
-    const ItemRec *items = a.items + (size_t)r * a.item_region;
-    const uint64_t *masks = a.region_masks + (size_t)r * a.mask_stride;
-    uint32_t base_slot = a.region_kept[r];  // (now the exclusive sum over the regions)
-    for (uint32_t cb = 0; cb < nchunks; cb += kPruneMaskCap) {
-        const uint32_t nc = min((uint32_t)kPruneMaskCap, nchunks - cb);
-        // exclusive sum of the chunks' popcounts: every thread a run of consecutive chunks, then the threads' sums
-        const uint32_t per = (nc + kThreads - 1) / kThreads, lo = min(nc, threadIdx.x * per), hi = min(nc, lo + per);
-        uint32_t mine = 0;
-        for (uint32_t c = lo; c < hi; ++c) {
-            before[c] = mine;
-            mine += (uint32_t)__popcll(masks[cb + c]);
+    const uint32_t sub = threadIdx.x & (kWriteLanes - 1), c = (blockIdx.x * kThreads + threadIdx.x) / kWriteLanes;
+    const bool live = c < a.n_chunks;
+    const uint2 d = live ? a.chunk_dir[c] : make_uint2(0, 0);
+    uint32_t base_slot = live ? a.chunk_group[c / kChunkGroup] + a.chunk_kept[c] : 0u;
+    const uint32_t nwords = d.y ? ((d.x & 63u) + d.y + 63u) / 64u : 0u;
+    const ItemRec *items = a.items + (d.x & ~63u);
+    const uint64_t *masks = slot_mask_word(a, d.x);
+    // (the loop bound is the largest of the wavefront's eight chunks: the cross-lane steps below need every lane)
+    uint32_t most = nwords;
+    for (int off = kWriteLanes; off < 64; off <<= 1) most = max(most, (uint32_t)__shfl_xor((int)most, off, 64));
+    for (uint32_t w0 = 0; w0 < most; w0 += kWriteLanes) {
+        const uint32_t w = w0 + sub;
+        uint64_t km = w < nwords ? masks[w] & chunk_word_bits(d.x, d.y, w) : 0ull;
+        const uint32_t cnt = (uint32_t)__popcll(km);
+        uint32_t incl = cnt;
+        for (int off = 1; off < kWriteLanes; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off, kWriteLanes);
+            if ((int)sub >= off) incl += up;
         }
-        uint32_t incl = mine;  // inclusive scan over the wavefront's threads, then over the wavefronts
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
-            if ((int)lane >= off) incl += up;
-        }
-        if (lane == 63) wave_sum[wave] = incl;
-        __syncthreads();
-        uint32_t wave_before = 0, total = 0;
-        for (uint32_t w = 0; w < kThreads / 64; ++w) {
-            if (w < wave) wave_before += wave_sum[w];
-            total += wave_sum[w];
-        }
-        const uint32_t thread_before = wave_before + incl - mine;
-        for (uint32_t c = lo; c < hi; ++c) before[c] += thread_before;
-        __syncthreads();
-        for (uint32_t c = wave; c < nc; c += kThreads / 64) {
-            const uint64_t km = masks[cb + c];
-            if ((km >> lane) & 1) {
-                const ItemRec rec = items[(size_t)(cb + c) * 64 + lane];
-                const uint32_t slot = base_slot + before[c] + lanes_below(km);
-                if (slot < a.surv_item_cap) {
-                    a.skeys[0][slot] = ((uint64_t)rec.g << 3) | item_phase(rec.info);
-                    a.sinfo[0][slot] = rec.info;
-                }
+        uint32_t slot = base_slot + incl - cnt;
+        while (km) {  // four kept items at a time: their loads fly together
+            ItemRec rec[4];
+            bool have[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                have[u] = km != 0;
+                const uint32_t bit = have[u] ? (uint32_t)__builtin_ctzll(km) : 0u;
+                km &= km - 1;  // (0 stays 0)
+                if (have[u]) rec[u] = items[(size_t)w * 64 + bit];
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (have[u] && slot + u < a.surv_item_cap) {
+                    a.skeys[0][slot + u] = ((uint64_t)rec[u].g << 3) | item_phase(rec[u].info);
+                    a.sinfo[0][slot + u] = rec[u].info;
+                }
+            slot += 4;
         }
-        __syncthreads();
-        base_slot += total;
+        base_slot += (uint32_t)__shfl((int)incl, kWriteLanes - 1, kWriteLanes);
     }
 }
 
@@ -3014,8 +3120,9 @@ hipError_t launch_prune_ordered(const BatchArgs &a, hipStream_t s) {
         hipLaunchKernelGGL(k_prune_summary, dim3((1u << 24) / 32 / 4 / kThreads), dim3(kThreads), 0, s, a.adder_bitmap, a.adder_summary);
     }
     hipLaunchKernelGGL(k_prune_count, dim3(a.n_regions), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL(k_prune_chunks, dim3((a.n_chunks + kChunkGroup - 1) / kChunkGroup), dim3(kChunkGroup), 0, s, a);
     hipLaunchKernelGGL(k_prune_offsets, dim3(1), dim3(1024), 0, s, a);
-    hipLaunchKernelGGL(k_prune_write, dim3(a.n_regions), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL(k_prune_write, dim3((a.n_chunks + kThreads / kWriteLanes - 1) / (kThreads / kWriteLanes)), dim3(kThreads), 0, s, a);
     return hipGetLastError();
 }
 

@@ -50,6 +50,7 @@ enum : int {
     kCntGeneralStrips, // scan: strips converted sample by sample (first / last strips, unaligned input)
     kCntFixedStrips,   // scan, UC8: strips with samples whose magnitude the radial table cannot hold (patched from the full table)
     kCntSplitStrips,   // scan: times a strip was taken again in more parts because an LDS queue overflowed
+    kCntSuperChunks,   // scan: super-chunks (kScanWavesPerGroup chunks each) handed out beyond every workgroup's first one
     kCntCount = 20,
     // debug builds (RSB_STAGE_CLOCKS) and ablation runs only
     kDbgClkConvert = 20, kDbgClkEdge, kDbgClkGate, kDbgClkDf, kDbgClkSlice, kDbgStrips, kDbgGateBatches, kDbgDfBatches, kDbgSliceBatches,
@@ -84,11 +85,16 @@ struct BatchArgs {
     uint32_t item_region;
     uint32_t n_regions;
     uint32_t shared_cap;
-    uint32_t *region_counts; // items written per wave region
-    uint32_t *region_kept;   // ordered prune: kept items per region, then their exclusive sum
-    uint64_t *region_masks;  // ... and one keep mask per 64 items, mask_stride masks per region
+    uint32_t *region_counts; // items written per wave region (the runs of its chunks one behind the other)
+    uint32_t *region_kept;   // (kept items per region: a by-product of k_prune_count)
+    uint64_t *region_masks;  // ordered prune: one keep mask per 64 item slots, mask_stride (= item_region / 64) masks per region
     uint32_t mask_stride;
-    uint32_t strips_per_wave;// every scan wavefront takes this many consecutive strips
+    // The scan hands out the strips in CHUNKS of chunk_strips consecutive strips (chunk c = strips [c * chunk_strips, ...)), taken by
+    // whichever wavefront is free next; a chunk's items are one sorted run inside its wavefront's region, found through chunk_dir.
+    uint32_t chunk_strips, n_chunks;
+    uint2 *chunk_dir;        // per chunk: {first item slot (global index into items), items}
+    uint32_t *chunk_kept;    // ordered prune: kept items of the chunks before this one within its group of 256 chunks
+    uint32_t *chunk_group;   // ... and kept items before every such group (n_chunks / 256 + 1 entries)
     uint32_t surv_item_cap;
     uint64_t *skeys[2];    // kept items: sort key g << 3 | phase (ping-pong buffers for the radix sort)
     uint32_t *sinfo[2];    // ... and their info words
@@ -106,6 +112,7 @@ struct BatchArgs {
     int keep_all;            // prune keeps every item (filter owned by the caller)
     int debug_flags;         // ablation only (RSB_ABL): 1 skip classify, 2 skip slicing loads, 4 skip reductions
     int stage_limit;         // debug/ablation only (RSB_STAGE_LIMIT): stop the scan kernel after stage k
+    uint64_t *wave_times;    // debug only (RSB_WAVE_TIMES): per scan wavefront {start, end (100 MHz ticks), XCC id << 32 | HW_ID, strips taken}
 };
 
 // The sequential half on the device (DESIGN.md "device replay"): the greedy scan of demod_2400.c:289-374
