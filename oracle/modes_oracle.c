@@ -912,6 +912,52 @@ static size_t run_blocks(orc_ctx *c, const void *iq, const uint16_t *mags, const
     return c->nout;
 }
 
+/* ------------------------------------------------------------------ a chain of mag_bufs as a hardware driver builds it
+ * (sdr_bladerf.c:322-404, without the USB framing): every buffer has its own length (<= 131072) and sampleTimestamp, its
+ * overlap is ALWAYS the 326 samples behind the previous buffer's data (:323-324: data + length of the ring slot before it,
+ * zeros before the first -- the ring is calloc'ed, readsb.c:198-207 -- and part of that buffer's own overlap when it was
+ * shorter than 326), the converter runs once per sub-block of sub_len samples and the buffer's means are the averages of
+ * the sub-blocks' means (:385-390, 403-404).  Both demodulators run once per buffer (readsb.c:883-886). */
+size_t orc_run_bufs(orc_ctx *c, const void *iq, const orc_buf *bufs, size_t nbufs, uint32_t sub_len, orc_msg *out, size_t cap) {
+    const unsigned bps = (c->format == ORC_UC8) ? 2 : 4;
+    uint16_t *buf[2];
+    uint32_t length[2] = {0, 0};
+    for (int i = 0; i < 2; ++i)
+        buf[i] = calloc(ORC_BLOCK_SAMPLES + ORC_TRAILING, sizeof (uint16_t));
+    c->out = out;
+    c->cap = cap;
+    c->nout = 0;
+    int cur = 0;
+    for (size_t k = 0; k < nbufs; ++k) {
+        uint16_t *data = buf[cur], *last = buf[cur ^ 1];
+        const uint32_t len = bufs[k].length > ORC_BLOCK_SAMPLES ? ORC_BLOCK_SAMPLES : bufs[k].length;
+        memcpy(data, last + length[cur ^ 1], ORC_TRAILING * sizeof (uint16_t));
+        double mean_level = 0, mean_power = 0;
+        unsigned blocks = 0;
+        const uint32_t step = sub_len ? sub_len : len;
+        for (uint32_t off = 0; off < len; off += step, ++blocks) {
+            const uint32_t n = len - off < step ? len - off : step;
+            double ml = 0, mp = 0;
+            orc_convert(c, (const uint8_t *) iq + (bufs[k].start + off) * bps, &data[ORC_TRAILING + off], n, &ml, &mp);
+            mean_level += ml;
+            mean_power += mp;
+        }
+        if (!blocks)
+            continue; /* nothing converted: the buffer is not published (:398) */
+        mean_level /= blocks;
+        mean_power /= blocks;
+        length[cur] = len;
+        demod2400(c, data, len, bufs[k].sample_timestamp);
+        if (c->modeac)
+            demod2400AC(c, data, len, bufs[k].sample_timestamp, mean_level, mean_power);
+        cur ^= 1;
+    }
+    free(buf[0]);
+    free(buf[1]);
+    c->out = NULL;
+    return c->nout;
+}
+
 size_t orc_run_stream(orc_ctx *c, const void *iq, uint64_t nsamples, orc_msg *out, size_t cap) {
     return run_blocks(c, iq, NULL, NULL, nsamples, out, cap);
 }

@@ -67,6 +67,15 @@ void orc_reset(orc_ctx *c); /* filter, converter state, stats, stream position *
 size_t orc_run_stream(orc_ctx *c, const void *iq, uint64_t nsamples, orc_msg *out, size_t cap);
 /* the same block loop on magnitudes the caller converted (block_means: mean level / power per 131072-sample block, or NULL) */
 size_t orc_run_mag_stream(orc_ctx *c, const uint16_t *mags, const double *block_means, uint64_t nsamples, orc_msg *out, size_t cap);
+/* a chain of mag_bufs of the caller's geometry (a hardware driver's: sdr_bladerf.c:322-404): buffer k = samples
+ * [start, start + length) of iq with its own sampleTimestamp; converter calls per sub_len samples (0: one per buffer),
+ * the buffer's means = the average of the calls' means */
+typedef struct {
+    uint64_t start;
+    uint64_t length;
+    uint64_t sample_timestamp;
+} orc_buf;
+size_t orc_run_bufs(orc_ctx *c, const void *iq, const orc_buf *bufs, size_t nbufs, uint32_t sub_len, orc_msg *out, size_t cap);
 void orc_get_stats(const orc_ctx *c, orc_stats *st);
 
 /* pieces, for unit tests */

@@ -17,6 +17,12 @@
  *   demodv  (same arguments)                                       the same with Modes.net_verbatim set; behind the records: msg[14] as
  *                                                                 delivered and verbatim[14] (mode_s.c:427-430) of every message
  *
+ *   demodbufs <fmt> <nfix> <modeac> <dcfilter> <sublen> <in.iq> <bufs.bin> <out.bin>
+ *                                                                 a chain of mag_bufs of the caller's geometry, as a hardware driver
+ *                                                                 builds it (sdr_bladerf.c:322-404 without the USB framing): bufs.bin =
+ *                                                                 {u64 start, u64 length, u64 sampleTimestamp} per buffer; the converter is
+ *                                                                 called per sublen samples and the buffer's means are the calls' averages
+ *
  * Built a second time as oracle/_ref/ref_harness_gpu (-DGPU_PATH): the SAME harness and reference objects, but with
  * demod_2400.o and convert.o replaced by integration/gpu_path.c + libreadsb_amd.so -- the link-level drop-in test.
  *   convert <fmt> <dcfilter> <chunk> <in.iq> <out.bin>           magnitudes + per-call means
@@ -198,6 +204,85 @@ static void run_stream(input_format_t fmt, const uint8_t *iq, size_t nbytes, int
 #endif
 }
 
+/* sdr_bladerf.c:322-404 without the framing: the reference's converter and demodulators on buffers of any length */
+static void run_bufs(input_format_t fmt, const uint8_t *iq, const uint64_t *bufs, size_t nbufs, unsigned sublen, int modeac) {
+    unsigned bps = (fmt == INPUT_UC8) ? 2 : 4;
+    struct converter_state *st = NULL;
+    iq_convert_fn conv = init_converter(fmt, Modes.sample_rate, Modes.dc_filter, &st);
+    if (!conv) exit(2);
+    struct mag_buf ring[2];
+    memset(ring, 0, sizeof (ring));
+    for (int i = 0; i < 2; ++i)
+        ring[i].data = calloc(MODES_MAG_BUF_SAMPLES + Modes.trailing_samples, sizeof (uint16_t));
+    int cur = 0;
+    for (size_t k = 0; k < nbufs; ++k) {
+        struct mag_buf *outbuf = &ring[cur], *lastbuf = &ring[cur ^ 1];
+        uint64_t start = bufs[3 * k], len = bufs[3 * k + 1];
+        if (len > MODES_MAG_BUF_SAMPLES) len = MODES_MAG_BUF_SAMPLES;
+        memcpy(outbuf->data, lastbuf->data + lastbuf->length, Modes.trailing_samples * sizeof (uint16_t)); /* :324 */
+        outbuf->dropped = 0;
+        outbuf->length = 0;
+        outbuf->mean_level = outbuf->mean_power = 0;
+        outbuf->sampleTimestamp = bufs[3 * k + 2];
+        unsigned blocks_processed = 0, step = sublen ? sublen : (unsigned) len;
+        while (outbuf->length < len) {
+            unsigned n = (len - outbuf->length < step) ? (unsigned) (len - outbuf->length) : step;
+            double mean_level, mean_power;
+            conv((void *) (iq + (start + outbuf->length) * bps), &outbuf->data[Modes.trailing_samples + outbuf->length], n, st, &mean_level, &mean_power); /* :387 */
+            outbuf->length += n;
+            outbuf->mean_level += mean_level;
+            outbuf->mean_power += mean_power;
+            ++blocks_processed;
+        }
+        if (!blocks_processed)
+            continue;
+        outbuf->mean_level /= blocks_processed; /* :403-404 */
+        outbuf->mean_power /= blocks_processed;
+        demodulate2400(outbuf);
+        if (modeac)
+            demodulate2400AC(outbuf);
+        cur ^= 1;
+    }
+    free(ring[0].data);
+    free(ring[1].data);
+#ifdef GPU_PATH
+    cleanup_converter(st);
+#else
+    free(st);
+#endif
+}
+
+static int write_records(const char *path) {
+    FILE *f = fopen(path, "wb");
+    if (!f) { perror(path); return 2; }
+    uint64_t hdr[8] = {nrecs,
+        Modes.stats_current.demod_preambles,
+        Modes.stats_current.demod_rejected_bad,
+        Modes.stats_current.demod_rejected_unknown_icao,
+        Modes.stats_current.demod_accepted[0],
+        Modes.stats_current.demod_accepted[1],
+        Modes.stats_current.demod_accepted[2],
+        Modes.stats_current.demod_modeac};
+    fwrite(hdr, sizeof (hdr), 1, f);
+    fwrite(recs, sizeof (*recs), nrecs, f);
+    if (capture_verbatim) fwrite(verb, sizeof (*verb), nrecs, f);
+    fclose(f);
+    return 0;
+}
+
+static int cmd_demodbufs(int argc, char **argv) {
+    if (argc != 10) return 2;
+    input_format_t fmt = parse_fmt(argv[2]);
+    int nfix = atoi(argv[3]), modeac = atoi(argv[4]), dc = atoi(argv[5]);
+    unsigned sublen = (unsigned) atoi(argv[6]);
+    size_t nbytes, lbytes;
+    uint8_t *iq = slurp(argv[7], &nbytes);
+    uint64_t *bufs = slurp(argv[8], &lbytes);
+    init_modes(nfix, modeac, dc);
+    run_bufs(fmt, iq, bufs, lbytes / 24, sublen, modeac);
+    return write_records(argv[9]);
+}
+
 static int cmd_demod(int argc, char **argv) {
     if (argc != 8) return 2;
     input_format_t fmt = parse_fmt(argv[2]);
@@ -361,6 +446,7 @@ int main(int argc, char **argv) {
     int rc = 2;
     if (argc >= 2) {
         if (!strcmp(argv[1], "demod") || !strcmp(argv[1], "demodv")) rc = cmd_demod(argc, argv);
+        else if (!strcmp(argv[1], "demodbufs")) rc = cmd_demodbufs(argc, argv);
         else if (!strcmp(argv[1], "time")) rc = cmd_time(argc, argv);
         else if (!strcmp(argv[1], "stats")) rc = cmd_stats(argc, argv);
         else if (!strcmp(argv[1], "convert")) rc = cmd_convert(argc, argv);

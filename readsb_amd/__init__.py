@@ -284,6 +284,8 @@ class Channel:
         """rsb_collect_begin: the returned slice of `out` (pinned memory) holds the records only after collect_wait()."""
         n = _SZ()
         rc = self.l.rsb_collect_begin(self.h, out.ctypes.data, out.size, C.byref(n))
+        if rc != 0:
+            self.l.rsb_collect_wait(self.h)  # (on overflow the library leaves the copy of the first cap records in flight: not into a buffer we let go of)
         if rc == -4 and n.value > out.size:
             raise RsbError(f"rsb_collect_begin: {n.value} messages exceed cap {out.size}")
         self._check(rc, "rsb_collect_begin")

@@ -123,6 +123,7 @@ int setup_device(rsb_ctx *c) {
     }
     HIP_TRY(c, hipStreamCreateWithFlags(&c->replay_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
     for (void *&p : c->d_carry) HIP_TRY(c, hipMalloc(&p, kTrailing * 4));
     c->sort_temp_bytes = sort_temp_bytes(c->surv_item_cap);
     HIP_TRY(c, hipMalloc(&c->d_sort_temp, c->sort_temp_bytes));
@@ -269,6 +270,10 @@ int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devi
     b.chain_enqueued = true;
     b.chain_count_on_device = count_on_device;
     b.chain_to_host = false;
+    // A record copy that rsb_collect_begin left in flight reads the d_out of ITS slot; this chain writes this slot's.  The same
+    // slot only on one-slot contexts (dc_filter, SC16Q11 table): begin(k), submit(k + 1), prepare(k + 1) -- the chain then waits
+    // on the device for the copy, the host does not.
+    if (c->copy_in_flight && c->copy_slot == &b) HIP_TRY(c, hipStreamWaitEvent(s, c->copy_done, 0));
     HIP_TRY(c, hipEventRecord(b.rev[1], s));
     if (r.nblocks == 0) {
         HIP_TRY(c, hipEventRecord(b.rev[2], s));
@@ -478,6 +483,7 @@ void rsb_destroy(rsb_ctx *c) {
     for (hipEvent_t ev : c->many_args_read)
         if (ev) (void)hipEventDestroy(ev);
     if (c->addr_upload_done) (void)hipEventDestroy(c->addr_upload_done);
+    if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void *ptrs[] = {c->d_lut, c->d_radial, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
                     c->d_bitmap, c->d_summary, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
                     c->d_magbuf, c->d_wave_times, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge};
@@ -640,6 +646,8 @@ int rsb_filter_export(rsb_ctx *c, uint32_t *out, size_t cap, size_t *n_out) {
 // a batch onto the caller's stream in three parts, so that rsb_submit_many can put ONE scan launch between the first and the last
 // part of all its channels
 static int enqueue_before_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, hipStream_t s, bool record_start = true) {
+    // (one-slot contexts: a record copy still in flight may read this slot's item buffer -- a list merged with Mode A/C messages)
+    if (c->copy_in_flight && c->copy_slot == &b) HIP_TRY(c, hipStreamWaitEvent(s, c->copy_done, 0));
     HIP_TRY(c, hipMemsetAsync(b.d_counters, 0, kCntAlloc * sizeof(uint32_t), s));
     HIP_TRY(c, hipMemsetAsync(b.d_region_counts, 0, (size_t)a.n_regions * sizeof(uint32_t), s));
     b.scan_share = 1.0f;
@@ -1012,7 +1020,11 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
             n = nlist;
             const size_t ncopy = n < cap ? n : cap;
             if (list != b.d_out) HIP_TRY(c, hipStreamSynchronize(s));  // (a merged list: its kernel ran on the replay stream)
-            if (ncopy) HIP_TRY(c, hipMemcpyAsync(out, list, ncopy * sizeof(rsb_message), hipMemcpyDeviceToHost, c->copy_stream));
+            if (ncopy) {
+                HIP_TRY(c, hipMemcpyAsync(out, list, ncopy * sizeof(rsb_message), hipMemcpyDeviceToHost, c->copy_stream));
+                HIP_TRY(c, hipEventRecord(c->copy_done, c->copy_stream));
+                c->copy_slot = &b;
+            }
             collect_ahead(c);
             if (c->defer_copy_wait && ncopy)
                 c->copy_in_flight = true;  // rsb_collect_begin: the caller comes back with rsb_collect_wait

@@ -137,6 +137,8 @@ struct rsb_ctx {
     hipStream_t copy_stream = nullptr;    // the finished record list leaves on this one (a DMA copy beside whatever the kernels do)
     bool defer_copy_wait = false;         // rsb_collect_begin: leave the record copy in flight ...
     bool copy_in_flight = false;          // ... until rsb_collect_wait (or the next call that needs the copy stream idle)
+    hipEvent_t copy_done = nullptr;       // behind the last record copy on the copy stream
+    const rsb_slot *copy_slot = nullptr;  // the slot whose d_out that copy reads: a chain that writes it again waits for copy_done
     hipStream_t replay_stream = nullptr;  // sort / replay / copy-out run here, behind the batch's scan (event) and beside the next one's
     uint64_t stream_pos = 0;          // of the next batch to collect
     uint64_t submit_pos = 0;          // of the next batch to submit

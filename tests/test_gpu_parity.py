@@ -654,6 +654,36 @@ def test_prepare_and_fence_order_the_next_scan_on_the_device(built):
     ch.close()
 
 
+@pytest.mark.parametrize("name", list(TABLE_SCENARIOS))
+def test_one_slot_context_keeps_records_while_the_next_chain_is_enqueued(name, built):
+    """One-slot contexts (dc_filter, SC16Q11 table: one magnitude buffer, one set of result buffers): rsb_collect_begin leaves batch
+    k's record copy in flight, then batch k + 1 is submitted and its chain enqueued (rsb_collect_prepare) BEFORE rsb_collect_wait.
+    The chain and the scan write the buffers that copy reads; the library orders them on the device (the copy_done event).
+    Bit for bit against the oracle, batch by batch, with and without Mode A/C (whose merged list lives in the item buffer)."""
+    import torch
+
+    sc, kw = TABLE_SCENARIOS[name]
+    iq = generate(sc)
+    want, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"], q11_table_bits=kw["q11_table_bits"]).run_stream(iq)
+    nb = 2 * 131072
+    cuts = list(range(0, iq.shape[0], nb)) + [iq.shape[0]]
+    dev = torch.from_numpy(iq).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], q11_table_bits=kw["q11_table_bits"], max_batch_samples=nb)
+    bufs = [torch.empty((1 << 14) * 56, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE) for _ in range(2)]
+    got = []
+    ch.submit(dev.data_ptr(), cuts[1], stream)
+    for k in range(len(cuts) - 1):
+        out = ch.collect_begin(bufs[k % 2])
+        if k + 2 < len(cuts):
+            ch.submit(dev.data_ptr() + 4 * cuts[k + 1], cuts[k + 2] - cuts[k + 1], stream)
+            ch.collect_prepare()
+        ch.collect_wait()
+        got.append(out.copy())
+    ch.close()
+    assert first_mismatch(want, np.concatenate(got).view(REC_DTYPE)) is None
+
+
 def test_two_half_collect_error_behaviour(built):
     """rsb_collect_begin / _prepare / _fence without a submitted batch fail with RSB_ESTATE and a message; rsb_collect_wait without
     a copy in flight is a no-op; a pageable output buffer works (the call then simply blocks); a short buffer keeps the first
