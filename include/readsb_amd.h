@@ -61,6 +61,15 @@ typedef struct rsb_config {
     uint32_t scan_workgroups;  /* workgroups (= CUs) the scan kernel's persistent grid may take; 0 = one per CU of the device.
                                   Fewer leave CUs to the replay kernels of the previous batch (two batches in flight), and a
                                   very small number makes every wavefront walk many strips of a small input (tests) */
+    uint32_t block_samples;    /* samples per demodulator call, i.e. mag_buf.length of a full buffer: 0 = 131072 (MODES_MAG_BUF_SAMPLES,
+                                  what sdr_ifile.c / sdr_rtlsdr.c / sdr_plutosdr.c build).  A bladeRF buffer holds 524288 / block_size
+                                  sub-blocks of (block_size - 16) / 4 samples (sdr_bladerf.c:335-339): 129024 or 130048.  The greedy
+                                  skip, the Mode A/C scan and its noise level start fresh per buffer (demod_2400.c:88,371,484-487), so
+                                  the buffer length is part of the result.  A multiple of 8 in 4096..131072; batches are whole
+                                  numbers of such blocks; not with dc_filter or the SC16Q11 table converter */
+    uint32_t mean_sub_samples; /* 0, or: the converter is called once per this many samples and a buffer's mean level / power are
+                                  the averages of the calls' means (sdr_bladerf.c:385-390, 403-404).  A divisor of block_samples;
+                                  SC16 / SC16Q11 only */
 } rsb_config;
 
 /* Run the sequential half (best phase, decode, greedy skip, filter updates) on the host from the
@@ -278,19 +287,26 @@ typedef struct rsb_stream rsb_stream;
 typedef void (*rsb_stream_sink)(void *user, const rsb_message *msgs, size_t n);
 int rsb_stream_open(rsb_ctx *ctx, uint32_t blocks_per_batch, rsb_stream_sink sink, void *user, rsb_stream **out);
 int rsb_stream_push(rsb_stream *st, const void *iq_host, uint32_t nsamples, uint64_t dropped_before);
-/* The bladeRF's framing (sdr_bladerf.c:335-394): one transfer buffer as its stream callback receives it, `bytes` long, made of
+/* handle_bladerf_samples (sdr_bladerf.c:283-422): one transfer buffer as the bladeRF stream callback receives it, `bytes` long, made of
  * sub-blocks of block_size bytes = a 16-byte metadata header (magic 0x12344321, 64-bit hardware timestamp at +4, status flags at
- * +12, little endian) followed by (block_size - 16) / 4 SC16Q11 samples.  Headers are stripped and the samples staged back to
- * back; a wrong magic ends the buffer (the reference skips its rest, :347-353); *overruns receives the number of sub-blocks
- * flagged BLADERF_META_STATUS_OVERRUN.  A timestamp that is not the expected one means lost samples (:366-375): as the reference,
- * the part of THIS buffer before that sub-block is discarded, what was staged earlier is decoded, and the stream restarts at the
- * new position from a zero carry -- message timestamps keep following the hardware timestamp (timestamp / decimation samples
- * from the first buffer's).  rsb_stream_flush on such a stream submits whole 131072-sample blocks only.
- * PARITY UNPINNED: the handler needs libbladeRF and cannot run in the build container; what is tested is that the de-framed
- * stream decodes exactly as the same samples pushed plainly.  Known difference: the reference's mag_buf then holds
- * 131072 * 4 / block_size sub-blocks (e.g. 129024 samples) and its Mode A/C noise threshold uses the mean of the sub-block means
- * (:389-404); this library keeps 131072-sample blocks, so demodulate2400AC decisions near the threshold can differ (Mode S does
- * not depend on block boundaries).  Not available with dc_filter. */
+ * +12, little endian) followed by (block_size - 16) / 4 SC16Q11 samples.  The context must have the driver's buffer geometry:
+ * rsb_config.block_samples = the samples of one transfer buffer (bytes / block_size sub-blocks: 129024 for block_size 1024, 130048
+ * for 2048) and, with mode_ac, mean_sub_samples = those of one sub-block -- every transfer buffer then is one struct mag_buf of
+ * the reference: the greedy skip and the Mode A/C scan start fresh per buffer, and the Mode A/C noise level comes from the average
+ * of the sub-blocks' means (:385-390, 403-404).  The handler's state is kept as the reference keeps it: the expected timestamp
+ * starts at 0 = "none" (:289, 366), so unless the hardware counter starts at 0 the first sub-block ever is dropped by the mismatch the
+ * second one raises; a timestamp that is not the expected one (forwards or backwards) discards what THIS buffer held so far and
+ * restarts the buffer there (:366-375); a wrong magic value ends the buffer (:347-353).  Every buffer's overlap is the 326 samples
+ * behind the previously published buffer's data, whatever was lost in between (:323-324: this driver never zeroes it).  A buffer
+ * that comes out short ends the run of blocks: it is decoded as the last block of a ragged batch, and the next buffer starts a new
+ * run at its own position (rsb_seek with that overlap as the carry).  Message timestamps follow the hardware timestamp:
+ * sampleTimestamp = timestamp * 12e6 / sample_rate / decimation (:382; timestamps that are not multiples of the decimation are
+ * rounded down to a sample).  *overruns receives the number of sub-blocks flagged BLADERF_META_STATUS_OVERRUN (only reported by
+ * the reference).  rsb_stream_flush on such a stream submits whole blocks only.
+ * Parity: the reference's converter and demodulators, unmodified, run on the chain of buffers the handler builds for a transfer
+ * sequence with all of these cases (oracle/_ref/ref_harness demodbufs -> tests/golden/demod_bladerf_chain.npz); the handler's own
+ * framing loop needs libbladeRF and cannot be built here, so the chain itself comes from a test-side restatement of :339-404
+ * (tests/scenarios.py: bladerf_model).  Not available with dc_filter (rsb_seek is not). */
 int rsb_stream_push_bladerf(rsb_stream *st, const void *buf, size_t bytes, uint32_t block_size, uint32_t decimation, uint32_t *overruns);
 int rsb_stream_flush(rsb_stream *st);
 int rsb_stream_close(rsb_stream *st);   /* flush, then free the stream (not the context) */

@@ -121,6 +121,25 @@ class Oracle:
         self.lib.orc_get_stats(self.h, st.ctypes.data)
         return out[:got].copy(), dict(zip(STAT_NAMES, (int(x) for x in st)))
 
+    def run_bufs(self, iq: np.ndarray, bufs, sub_len: int = 0):
+        """orc_run_bufs: a chain of mag_bufs [(first sample, length, sampleTimestamp)] of a hardware driver's geometry, the
+        converter called per sub_len samples (sdr_bladerf.c:322-404) -> (messages, stats)"""
+        raw = iq_bytes(iq)
+        b = np.ascontiguousarray(np.array(bufs, dtype=np.uint64).reshape(-1, 3))
+        self.lib.orc_run_bufs.restype = C.c_size_t
+        self.lib.orc_run_bufs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t]
+        cap = max(1024, raw.size // self.bps // 100)
+        while True:
+            out = np.zeros(cap, dtype=REC_DTYPE)
+            self.reset()
+            got = self.lib.orc_run_bufs(self.h, raw.ctypes.data, b.ctypes.data, b.shape[0], int(sub_len), out.ctypes.data, cap)
+            if got <= cap:
+                break
+            cap = got
+        st = np.zeros(7, dtype=np.uint64)
+        self.lib.orc_get_stats(self.h, st.ctypes.data)
+        return out[:got].copy(), dict(zip(STAT_NAMES, (int(x) for x in st)))
+
     def run_mag_stream(self, mags: np.ndarray, block_means: np.ndarray | None = None):
         """The demodulators on magnitudes converted elsewhere (fresh filter): -> messages."""
         mags = np.ascontiguousarray(mags, dtype=np.uint16)
@@ -221,6 +240,22 @@ class RefHarness:
             return recs.copy(), st, raw[64 + 56 * n:].reshape(n, 2, 14).copy()
         assert raw.size == 64 + 56 * n
         return recs.copy(), st
+
+    @staticmethod
+    def demodbufs(iq: np.ndarray, bufs, sub_len=0, fmt="UC8", nfix=1, modeac=False, dc_filter=False):
+        """The reference's converter and demodulators on a chain of mag_bufs [(first sample, length, sampleTimestamp)], the converter
+        called per sub_len samples and the means averaged as sdr_bladerf.c:385-404 does -> (records, stats)"""
+        with tempfile.TemporaryDirectory() as d:
+            fin, fb, fout = os.path.join(d, "in.iq"), os.path.join(d, "bufs.bin"), os.path.join(d, "out.bin")
+            iq_bytes(iq).tofile(fin)
+            np.array(bufs, dtype="<u8").reshape(-1, 3).tofile(fb)
+            subprocess.run([REF_BIN, "demodbufs", fmt, str(int(nfix)), str(int(modeac)), str(int(dc_filter)), str(int(sub_len)), fin, fb, fout],
+                           check=True, stderr=subprocess.DEVNULL)
+            raw = np.fromfile(fout, dtype=np.uint8)
+        hdr = raw[:64].view("<u8")
+        n = int(hdr[0])
+        assert raw.size == 64 + 56 * n
+        return raw[64:64 + 56 * n].view(REC_DTYPE).copy(), dict(zip(STAT_NAMES, (int(x) for x in hdr[1:8])))
 
     @staticmethod
     def stats(iq: np.ndarray, fmt="UC8", nfix=1, modeac=False, dc_filter=False) -> dict:

@@ -34,7 +34,7 @@ assert MSG_DTYPE.itemsize == 56 and CAND_DTYPE.itemsize == 96 and AC_DTYPE.items
 class Config(C.Structure):
     _fields_ = [("input_format", C.c_int32), ("dc_filter", C.c_int32), ("fix_bits", C.c_int32), ("mode_ac", C.c_int32),
                 ("device", C.c_int32), ("queue_div", C.c_uint32), ("max_batch_samples", C.c_uint64),
-                ("flags", C.c_uint32), ("scan_workgroups", C.c_uint32)]
+                ("flags", C.c_uint32), ("scan_workgroups", C.c_uint32), ("block_samples", C.c_uint32), ("mean_sub_samples", C.c_uint32)]
 
 
 FLAG_HOST_REPLAY = 1
@@ -199,14 +199,14 @@ class Channel:
     """One receiver channel (rsb_ctx)."""
 
     def __init__(self, fmt="UC8", fix_bits=1, mode_ac=False, dc_filter=False, device=0, max_batch_samples=1 << 24, queue_div=0,
-                 host_replay=False, exact_stats=False, defer_prune=False, scan_workgroups=0, q11_table_bits=0):
+                 host_replay=False, exact_stats=False, defer_prune=False, scan_workgroups=0, q11_table_bits=0, block_samples=0, mean_sub_samples=0):
         self.l = lib()
         self.fmt = fmt
         self.bps = 2 if fmt == "UC8" else 4
         cfg = Config(FORMATS[fmt], int(dc_filter), int(fix_bits), int(mode_ac), int(device), int(queue_div), int(max_batch_samples),
                      (FLAG_HOST_REPLAY if host_replay else 0) | (FLAG_EXACT_STATS if exact_stats else 0) | (FLAG_DEFER_PRUNE if defer_prune else 0)
                      | ((int(q11_table_bits) & 15) << 8),  # RSB_FLAG_SC16Q11_TABLE(bits): a reference built with -DSC16Q11_TABLE_BITS
-                     int(scan_workgroups))
+                     int(scan_workgroups), int(block_samples), int(mean_sub_samples))
         h = _VP()
         rc = self.l.rsb_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -320,10 +320,10 @@ class Channel:
         self._check(self.l.rsb_process_host(self.h, raw.ctypes.data, ns, out.ctypes.data, cap, C.byref(n)), "rsb_process_host")
         return out[:n.value].copy()
 
-    def process_stream_host(self, iq: np.ndarray, batch_blocks: int) -> np.ndarray:
-        """Feed a recording in batches of batch_blocks x 131072 samples (last one partial)."""
+    def process_stream_host(self, iq: np.ndarray, batch_blocks: int, block: int = BLOCK) -> np.ndarray:
+        """Feed a recording in batches of batch_blocks x 131072 samples (last one partial); block: rsb_config.block_samples of the context."""
         raw = np.ascontiguousarray(iq).view(np.uint8).reshape(-1, self.bps)
-        step = batch_blocks * BLOCK
+        step = batch_blocks * block
         parts = []
         pos = 0
         while True:

@@ -83,7 +83,7 @@ int setup_device(rsb_ctx *c) {
     c->defer_prune = (c->cfg.flags & RSB_FLAG_DEFER_PRUNE) != 0;
     if (c->exact_stats) c->surv_cap = (uint32_t)cap;  // every gated offset (about 1 % of the samples on noise) becomes a candidate record
     c->ac_cap = (uint32_t)(cap / 4 < 4096 ? 4096 : cap / 4);
-    c->nblocks_cap = (nmax + kBlock - 1) / kBlock + 1;
+    c->nblocks_cap = (nmax + c->block_len - 1) / c->block_len + 1;
     c->scan_grid = scan_grid_size(c->cfg.device);
     if (const char *e = std::getenv("RSB_STAGE_LIMIT")) c->stage_limit = std::atoi(e);  // ablation timing only
     if (const char *e = std::getenv("RSB_ABL")) c->debug_flags = std::atoi(e);
@@ -131,6 +131,7 @@ int setup_device(rsb_ctx *c) {
     HIP_TRY(c, hipMalloc((void **)&c->d_surv, (size_t)c->surv_cap * sizeof(Survivor)));
     HIP_TRY(c, hipMalloc((void **)&c->d_bitmap, (1u << 24) / 8));
     HIP_TRY(c, hipMalloc((void **)&c->d_summary, kSummaryWords * sizeof(uint32_t)));
+    if (c->mean_sub) HIP_TRY(c, hipMalloc((void **)&c->d_sub_means, ((size_t)(nmax / c->mean_sub) + 2) * 2 * sizeof(double)));
     HIP_TRY(c, hipMalloc((void **)&c->d_dc_state, sizeof(double2)));
     HIP_TRY(c, hipMemset(c->d_dc_state, 0, sizeof(double2)));
     if (c->cfg.dc_filter || c->q11_table_bits) HIP_TRY(c, hipMalloc((void **)&c->d_magbuf, (size_t)nmax * sizeof(uint16_t) + 16));
@@ -261,7 +262,8 @@ int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devi
     r.blk_base = b.d_blk_base;
     r.blk_counts = b.d_blk_counts;
     r.blk_start = b.d_blk_start;
-    r.nblocks = (uint32_t)((b.pending_n + kBlock - 1) / kBlock);
+    r.nblocks = (uint32_t)((b.pending_n + c->block_len - 1) / c->block_len);
+    r.block_len = c->block_len;
     r.new_adders = b.d_new_adders;
     r.new_adders_cap = rsb_ctx::kNewAddersCap;
     r.out = b.d_out;
@@ -460,6 +462,17 @@ int rsb_create(const rsb_config *cfg, rsb_ctx **out) {
             return RSB_EINVAL;
         }
     }
+    if (cfg->block_samples || cfg->mean_sub_samples) {
+        // the buffer geometry of a hardware driver (sdr_bladerf.c:335-404): whole 16-byte pieces of IQ per buffer, at most MODES_MAG_BUF_SAMPLES
+        const uint32_t L = cfg->block_samples ? cfg->block_samples : kBlock, sub = cfg->mean_sub_samples;
+        const bool float_fmt = cfg->input_format == RSB_SC16 || cfg->input_format == RSB_SC16Q11;
+        if (L > kBlock || L < 4096 || L % 8 != 0 || cfg->dc_filter || RSB_FLAG_SC16Q11_TABLE_BITS_OF(cfg->flags) ||
+            (sub && (!float_fmt || L % sub != 0 || sub < 8))) {
+            std::fprintf(stderr, "readsb_amd: rsb_config.block_samples must be a multiple of 8 in 4096..131072 (no dc_filter, no SC16Q11 table), "
+                                 "mean_sub_samples a divisor of it (SC16 / SC16Q11 only)\n");
+            return RSB_EINVAL;
+        }
+    }
     rsb_ctx *c = new (std::nothrow) rsb_ctx(*cfg);
     if (!c) return RSB_ENOMEM;
     int rc = setup_device(c);
@@ -486,7 +499,7 @@ void rsb_destroy(rsb_ctx *c) {
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void *ptrs[] = {c->d_lut, c->d_radial, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
                     c->d_bitmap, c->d_summary, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
-                    c->d_magbuf, c->d_wave_times, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge};
+                    c->d_magbuf, c->d_sub_means, c->d_wave_times, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge};
     for (rsb_slot &b : c->slots) {
         void *sp[] = {b.d_out, b.d_blk_counts, b.d_blk_start, b.d_blk_base, b.d_new_adders, b.d_items, b.d_region_counts, b.d_region_kept, b.d_region_masks, b.d_chunk_dir, b.d_chunk_kept, b.d_chunk_group, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
         for (void *p : sp)
@@ -588,7 +601,8 @@ int rsb_seek(rsb_ctx *c, uint64_t stream_pos, const void *carry, int carry_on_de
         c->err = "rsb_seek: a batch is pending";
         return RSB_ESTATE;
     }
-    if (stream_pos % kBlock != 0) {
+    // (a source with its own buffer geometry restarts its buffers wherever its driver does, sdr_bladerf.c:366-375: any position)
+    if (!c->cfg.block_samples && stream_pos % kBlock != 0) {
         c->err = "rsb_seek: stream position is not a multiple of 131072";
         return RSB_EINVAL;
     }
@@ -676,11 +690,18 @@ static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint6
     if ((c->run_ac || c->exact_stats) && nsamples) {
         // mag_buf.mean_level / mean_power of every block: demodulate2400AC's noise level (demod_2400.c:484-485) and the
         // noise power statistic (:378-382)
-        const size_t nblk = (nsamples + kBlock - 1) / kBlock;
+        const size_t nblk = (nsamples + c->block_len - 1) / c->block_len;
         BatchArgs ac = a;
         if (!ac.block_means && (a.fmt == kFmtSC16 || a.fmt == kFmtSC16Q11)) {
             // the float converters' block means (convert.c:226-262): exact only in sample order
-            HIP_TRY(c, launch_block_means_float(a.fmt, a.iq, nsamples, kBlock, b.d_block_means, s));
+            if (c->mean_sub) {
+                // ... of a driver that converts a buffer in sub-blocks and averages their means (sdr_bladerf.c:385-390, 403-404)
+                const uint32_t nsub = (uint32_t)((nsamples + c->mean_sub - 1) / c->mean_sub);
+                HIP_TRY(c, launch_block_means_float(a.fmt, a.iq, nsamples, c->mean_sub, c->d_sub_means, s));
+                HIP_TRY(c, launch_means_average(c->d_sub_means, nsub, c->block_len / c->mean_sub, b.d_block_means, (uint32_t)nblk, s));
+            } else {
+                HIP_TRY(c, launch_block_means_float(a.fmt, a.iq, nsamples, c->block_len, b.d_block_means, s));
+            }
             ac.block_means = b.d_block_means;
         }
         if (!ac.block_means) HIP_TRY(c, hipMemsetAsync(b.d_block_sums, 0, nblk * 2 * sizeof(uint64_t), s));
@@ -690,7 +711,7 @@ static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint6
             HIP_TRY(c, launch_block_sums(ac, s));
         b.means_on_device = ac.block_means;
     }
-    if (!c->block_mode && nsamples % kBlock == 0 && nsamples) {
+    if (!c->block_mode && nsamples % c->block_len == 0 && nsamples) {
         // the next batch's 326-sample overlap (sdr_ifile.c:199-201)
         const unsigned bps = (a.fmt == kFmtUC8 || a.fmt == kFmtMag16) ? 2 : 4;
         const unsigned k = (c->submitted + 1) % rsb_ctx::kCarries;
@@ -708,7 +729,7 @@ static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint6
         c->submit_pos += nsamples;
         // a short batch ends the recording, and so does an empty one (the reference publishes a zero-length block only at EOF,
         // sdr_ifile.c:213-225): nothing may follow it without rsb_seek / rsb_reset, so no carry is needed behind it
-        if (nsamples == 0 || nsamples % kBlock != 0) c->submit_finished = true;
+        if (nsamples == 0 || nsamples % c->block_len != 0) c->submit_finished = true;
     }
     return RSB_OK;
 }
@@ -719,8 +740,8 @@ static int submit_checks(rsb_ctx *c, const void *iq_dev, uint64_t nsamples) {
         c->err = c->nslots == 1 ? "rsb_submit: previous batch not collected" : "rsb_submit: four batches already in flight: collect one first";
         return RSB_ESTATE;
     }
-    if (c->submit_finished || c->submit_pos % kBlock != 0) {
-        c->err = "rsb_submit: stream position is not a multiple of 131072 (only the last batch may be partial)";
+    if (c->submit_finished) {
+        c->err = "rsb_submit: the last batch was not a whole number of blocks (131072 samples, or rsb_config.block_samples): only the last batch of a recording may be";
         return RSB_ESTATE;
     }
     if (nsamples > c->cfg.max_batch_samples) {
@@ -867,7 +888,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         if (rc != RSB_OK) return rc;
     }
     const BatchArgs &a = b.pending_args;
-    const size_t nblocks = (size_t)((b.pending_n + kBlock - 1) / kBlock);
+    const size_t nblocks = (size_t)((b.pending_n + c->block_len - 1) / c->block_len);
     c->h_blk_counts.resize(nblocks + 1);
     int on_device = 0, direct_parts = 0;
     c->timing.replay_iterations = 0;
@@ -1075,7 +1096,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
                 c->h_blk_sums.resize(2 * nblocks);
                 HIP_TRY(c, hipMemcpy(c->h_blk_sums.data(), b.d_block_sums, c->h_blk_sums.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
                 for (size_t k = 0; k < nblocks; ++k) {
-                    const uint64_t len = std::min<uint64_t>(kBlock, b.pending_n - k * kBlock);
+                    const uint64_t len = std::min<uint64_t>(c->block_len, b.pending_n - k * c->block_len);
                     c->h_blk_mean_power[k] = (double)c->h_blk_sums[2 * k + 1] / 65535.0 / 65535.0 / (double)(unsigned)len;
                 }
             }
@@ -1117,7 +1138,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
 
     if (!c->block_mode) {
         c->stream_pos += b.pending_n;
-        if (b.pending_n == 0 || b.pending_n % kBlock != 0) c->finished = true;
+        if (b.pending_n == 0 || b.pending_n % c->block_len != 0) c->finished = true;
     }
 
     if (n_out) *n_out = n;
@@ -1348,14 +1369,14 @@ int rsb_get_batch_magnitudes(rsb_ctx *c, uint16_t *mag_host, uint64_t nsamples, 
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipMemcpy(mag_host, c->d_magbuf, (size_t)nsamples * sizeof(uint16_t), hipMemcpyDeviceToHost));
     if (block_means && c->run_ac) {
-        const size_t nblk = (size_t)((c->last_n + kBlock - 1) / kBlock);
+        const size_t nblk = (size_t)((c->last_n + c->block_len - 1) / c->block_len);
         if (c->cfg.dc_filter) {
             HIP_TRY(c, hipMemcpy(block_means, c->slots[0].d_block_means, nblk * 2 * sizeof(double), hipMemcpyDeviceToHost));
         } else {  // the table converter: from the blocks' integer sums (convert.c:321-327)
             std::vector<uint64_t> sums(2 * nblk);
             HIP_TRY(c, hipMemcpy(sums.data(), c->slots[0].d_block_sums, sums.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
             for (size_t k = 0; k < nblk; ++k) {
-                const uint64_t len = std::min<uint64_t>(kBlock, c->last_n - k * kBlock);
+                const uint64_t len = std::min<uint64_t>(c->block_len, c->last_n - k * c->block_len);
                 block_means[2 * k] = (double)sums[2 * k] / 65536.0 / (double)(unsigned)len;
                 block_means[2 * k + 1] = (double)sums[2 * k + 1] / 65535.0 / 65535.0 / (double)(unsigned)len;
             }

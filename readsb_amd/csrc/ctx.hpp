@@ -48,11 +48,17 @@ struct rsb_slot {
 struct rsb_ctx {
     explicit rsb_ctx(const rsb_config &c) : cfg(c), replay(c.fix_bits) {
         run_ac = c.mode_ac != 0;
+        block_len = c.block_samples ? c.block_samples : rsb::kBlock;
+        mean_sub = c.mean_sub_samples;
+        replay.set_block_len(block_len);
         std::memset(&timing, 0, sizeof(timing));
     }
 
     rsb_config cfg;
     rsb::Replayer replay;
+    uint32_t block_len = rsb::kBlock;  // samples per demodulator call (rsb_config.block_samples)
+    uint32_t mean_sub = 0;             // rsb_config.mean_sub_samples: the converter is called per this many samples, a block's means are the calls' averages
+    double *d_sub_means = nullptr;     // ... the calls' means of the pending batch
 
     // read-only device tables
     uint16_t *d_lut = nullptr;
@@ -224,6 +230,7 @@ struct rsb_ctx {
         a.stage_limit = stage_limit;
         a.debug_flags = debug_flags;
         a.wave_times = d_wave_times;
+        a.block_len = block_len;
         return a;
     }
 };

@@ -1672,8 +1672,8 @@ __global__ __launch_bounds__(kThreads) void k_replay_bounds(const ReplayArgs r) 
         else r.counters[kCntChanged] = 0;
     }
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i <= n_items; i += gridDim.x * kThreads) {
-        const int64_t prev = i == 0 ? -1 : (int64_t)min((uint64_t)r.nblocks, (r.keys[i - 1] >> 3) / kBlock);
-        const int64_t cur = i == n_items ? (int64_t)r.nblocks : (int64_t)min((uint64_t)r.nblocks, (r.keys[i] >> 3) / kBlock);
+        const int64_t prev = i == 0 ? -1 : (int64_t)min((uint64_t)r.nblocks, (r.keys[i - 1] >> 3) / r.block_len);
+        const int64_t cur = i == n_items ? (int64_t)r.nblocks : (int64_t)min((uint64_t)r.nblocks, (r.keys[i] >> 3) / r.block_len);
         for (int64_t b = prev + 1; b <= cur; ++b) r.blk_start[b] = i;
     }
 }
@@ -1866,7 +1866,7 @@ __global__ __launch_bounds__(kThreads) void k_replay_list(const ReplayArgs r, ui
         if (r.acc[i] == 0) continue;
         const uint32_t info = r.info[i], g = (uint32_t)(r.keys[i] >> 3);
         // message number -> item (k_replay_emit works message by message): accepted messages before the item's block + its rank there
-        const uint32_t place = r.blk_base[g / kBlock] + r.acc_rank[i];
+        const uint32_t place = r.blk_base[g / r.block_len] + r.acc_rank[i];
         if (place < n_items) r.acc_idx[place] = i;
         if (!combo_adds(item_combo(info))) continue;
         const uint32_t v = item_value(info), g1 = g + 1;
@@ -2469,10 +2469,10 @@ __global__ __launch_bounds__(kAcThreads) void k_modeac(const BatchArgs a, const 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     if constexpr (FMT == kFmtUC8) load_radial_table(lut, a.tab.uc8_radial, 0u, tid, kAcThreads);
     // persistent: a workgroup takes every gridDim.x-th block, so the table is set up once per CU and not once per block
-    const uint64_t nblk = (a.n + kBlock - 1) / kBlock;
+    const uint64_t nblk = (a.n + a.block_len - 1) / a.block_len;
     for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const uint64_t blk_start = blk * kBlock;
-    const uint32_t blk_len = (uint32_t)((a.n - blk_start < (uint64_t)kBlock) ? (a.n - blk_start) : (uint64_t)kBlock);
+    const uint64_t blk_start = blk * a.block_len;  // (a multiple of 8: the tiles below start on 16-byte boundaries of the IQ)
+    const uint32_t blk_len = (uint32_t)((a.n - blk_start < (uint64_t)a.block_len) ? (a.n - blk_start) : (uint64_t)a.block_len);
 
     // ---- pass 1: sum(mag), sum(mag^2) over the block's new samples iq[blk_start .. blk_start + blk_len)
     if (!a.block_means && !(a.debug_flags & 16)) {
@@ -3343,6 +3343,26 @@ hipError_t launch_block_means_float(int fmt, const void *iq, uint64_t n, uint64_
     });
 }
 
+// one thread per block: the block's sub-block means added up in order, divided by their number (sdr_bladerf.c:389-390, 403-404)
+__global__ void k_means_average(const double *sub, uint32_t nsub, uint32_t per_block, double *means, uint32_t nblocks) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t lo = b * per_block, hi = min(nsub, lo + per_block);
+    double level = 0, power = 0;
+    for (uint32_t k = lo; k < hi; ++k) {
+        level += sub[2 * k];
+        power += sub[2 * k + 1];
+    }
+    means[2 * b] = level / (double)(hi - lo);  // (the reference divides by an unsigned: the same conversion)
+    means[2 * b + 1] = power / (double)(hi - lo);
+}
+
+hipError_t launch_means_average(const double *sub_means, uint32_t nsub, uint32_t per_block, double *means, uint32_t nblocks, hipStream_t s) {
+    if (!nblocks) return hipSuccess;
+    hipLaunchKernelGGL(k_means_average, dim3((nblocks + 255) / 256), dim3(256), 0, s, sub_means, nsub, per_block, means, nblocks);
+    return hipGetLastError();
+}
+
 template <int FMT>
 static hipError_t launch_ac_kernel(const BatchArgs &a, int sums_only, hipStream_t s) {
     auto kern = k_modeac<FMT>;
@@ -3353,7 +3373,7 @@ static hipError_t launch_ac_kernel(const BatchArgs &a, int sums_only, hipStream_
     if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
     static const int forced = std::getenv("RSB_AC_GRID") ? std::atoi(std::getenv("RSB_AC_GRID")) : 0;  // A/B timing only
-    const uint64_t nblk = (a.n + kBlock - 1) / kBlock;
+    const uint64_t nblk = (a.n + a.block_len - 1) / a.block_len;
     uint64_t grid = forced > 0 ? (uint64_t)forced : (uint64_t)(cus > 0 ? cus : 256);
     if (grid > nblk) grid = nblk;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kAcThreads), sizeof(AcShared), s, a, sums_only);

@@ -112,6 +112,7 @@ struct BatchArgs {
     int keep_all;            // prune keeps every item (filter owned by the caller)
     int debug_flags;         // ablation only (RSB_ABL): 1 skip classify, 2 skip slicing loads, 4 skip reductions
     int stage_limit;         // debug/ablation only (RSB_STAGE_LIMIT): stop the scan kernel after stage k
+    uint32_t block_len;      // samples per demodulator call (mag_buf.length of a full buffer): 131072 unless the source builds other buffers
     uint64_t *wave_times;    // debug only (RSB_WAVE_TIMES): per scan wavefront {start, end (100 MHz ticks), XCC id << 32 | HW_ID, strips taken}
 };
 
@@ -135,6 +136,7 @@ struct ReplayArgs {
     uint32_t *blk_start;     // first item of every 131072-sample block, nblocks + 1 entries (launch_replay_bounds)
     uint32_t *blk_counts;    // accepted messages per 131072-sample block
     uint32_t nblocks;
+    uint32_t block_len;      // samples per block (BatchArgs::block_len)
     uint2 *new_adders;       // (g + 1, address) of every address learned in this batch
     uint32_t new_adders_cap;
     rsb_message *out;
@@ -205,6 +207,9 @@ hipError_t launch_modeac(const BatchArgs &a, hipStream_t s);
 hipError_t launch_block_sums(const BatchArgs &a, hipStream_t s);
 // SC16 / SC16Q11: per block of blk_len samples the reference's float32 running sums, as means (level, power)
 hipError_t launch_block_means_float(int fmt, const void *iq, uint64_t n, uint64_t blk_len, double *means, hipStream_t s);
+// means[b] := the average of the per_block consecutive entries of sub_means that belong to block b (a driver that converts a buffer in
+// sub-blocks and averages their means, sdr_bladerf.c:385-390, 403-404); the last block may hold fewer
+hipError_t launch_means_average(const double *sub_means, uint32_t nsub, uint32_t per_block, double *means, uint32_t nblocks, hipStream_t s);
 // --dcfilter converters (chunked linear-recurrence scan): n samples -> n magnitudes.  tile_sums / tile_start hold one double2 per 4096
 // samples (+1); z_state is the carried DC state (in: before sample 0, out: after sample n-1); block_means (optional) receives
 // the mean level / mean power of every 131072-sample block of the call

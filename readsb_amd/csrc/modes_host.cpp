@@ -467,15 +467,16 @@ void Replayer::run_batch(uint64_t g0, std::vector<Survivor> &surv, std::vector<A
     sort_by_g(ac);
     const bool exact = blk_mean_power != nullptr;
     std::vector<uint64_t> blk_scaled;  // exact statistics: sum_scaled_signal_power of every block (demod_2400.c:357)
-    if (exact) blk_scaled.assign(size_t((nsamples + kBlock - 1) / kBlock), 0);
+    const uint64_t L = block_len_;
+    if (exact) blk_scaled.assign(size_t((nsamples + L - 1) / L), 0);
     size_t is = 0, ia = 0;
     while (is < surv.size() || ia < ac.size()) {
         // the next 131072-sample block that holds anything; each block is one demodulate2400 call
         // followed by one demodulate2400AC call (readsb.c:883-886), so skip windows start fresh
         uint64_t blk = UINT64_MAX;
-        if (is < surv.size()) blk = (g0 + surv[is].g) / kBlock;
-        if (ia < ac.size()) blk = std::min(blk, (g0 + ac[ia].g) / kBlock);
-        const uint64_t blk_start = blk * kBlock, blk_end = blk_start + kBlock;
+        if (is < surv.size()) blk = surv[is].g / L;
+        if (ia < ac.size()) blk = std::min(blk, uint64_t(ac[ia].g / L));
+        const uint64_t blk_start = g0 + blk * L, blk_end = blk_start + L;
 
         uint64_t next_j = 0;  // first offset the greedy scan looks at again
         for (; is < surv.size() && g0 + surv[is].g < blk_end; ++is) {
@@ -516,7 +517,7 @@ void Replayer::run_batch(uint64_t g0, std::vector<Survivor> &surv, std::vector<A
             if (exact) {  // demod_2400.c:355-362
                 stats_.signal_power_sum += signal_power;
                 stats_.signal_power_count += uint64_t(signal_len);
-                blk_scaled[size_t((g - g0) / kBlock)] += scaled;
+                blk_scaled[size_t((g - g0) / L)] += scaled;
                 if (m.signal_level > stats_.peak_signal_power) stats_.peak_signal_power = m.signal_level;
                 if (m.signal_level > 0.50119) ++stats_.strong_signal_count;
             }
@@ -526,7 +527,7 @@ void Replayer::run_batch(uint64_t g0, std::vector<Survivor> &surv, std::vector<A
         replay_modeac_block(g0, blk_start, blk_end, ac, ia, stats_, out);
     }
     for (size_t b = 0; b < blk_scaled.size(); ++b) {  // demod_2400.c:378-382, once per demodulate2400 call
-        const uint64_t len = std::min<uint64_t>(kBlock, nsamples - b * kBlock);
+        const uint64_t len = std::min<uint64_t>(L, nsamples - b * L);
         const double sum_signal_power = blk_scaled[b] / 65535.0 / 65535.0;
         stats_.noise_power_sum += (blk_mean_power[b] * len - sum_signal_power);
         stats_.noise_power_count += len;
@@ -538,10 +539,10 @@ void Replayer::merge_modeac(uint64_t g0, const std::vector<rsb_message> &msgs, c
     sort_by_g(ac);
     size_t im = 0, ia = 0;
     for (size_t b = 0; b < nblocks; ++b) {
-        const uint64_t blk_start = g0 + b * kBlock;
+        const uint64_t blk_start = g0 + b * block_len_;
         out.insert(out.end(), msgs.begin() + im, msgs.begin() + im + blk_counts[b]);
         im += blk_counts[b];
-        replay_modeac_block(g0, blk_start, blk_start + kBlock, ac, ia, stats_, out);
+        replay_modeac_block(g0, blk_start, blk_start + block_len_, ac, ia, stats_, out);
     }
 }
 
@@ -549,9 +550,9 @@ void Replayer::modeac_messages(uint64_t g0, size_t nblocks, std::vector<AcCand> 
     sort_by_g(ac);
     size_t ia = 0;
     for (size_t b = 0; b < nblocks; ++b) {
-        const uint64_t blk_start = g0 + b * kBlock;
+        const uint64_t blk_start = g0 + b * block_len_;
         const size_t before = out.size();
-        replay_modeac_block(g0, blk_start, blk_start + kBlock, ac, ia, stats_, out);
+        replay_modeac_block(g0, blk_start, blk_start + block_len_, ac, ia, stats_, out);
         counts[b] = uint32_t(out.size() - before);
     }
 }

@@ -139,11 +139,14 @@ uint32_t uc8_radial_patch_p1();         // DeviceTables::uc8_patch_p1
 class Replayer {
 public:
     explicit Replayer(int nfix) : crc_(nfix) { reset(); }
+    // samples per demodulator call (one struct mag_buf): skip windows and Mode A/C runs start fresh at every multiple of it, counted
+    // from the batch's first sample (a batch starts on a buffer boundary)
+    void set_block_len(uint32_t n) { block_len_ = n ? n : kBlock; }
     void reset();
     IcaoFilter &filter() { return filter_; }
     const CrcTables &crc() const { return crc_; }
     rsb_stats &stats() { return stats_; }
-    // g0 = stream position of the batch (multiple of kBlock); records need not be sorted.
+    // g0 = stream position of the batch (the start of a block); records need not be sorted.
     // Exact-statistics mode (RSB_FLAG_EXACT_STATS): surv holds EVERY gated offset of the batch, and
     // blk_mean_power[b] = mag_buf.mean_power of block b of the nsamples-long batch; the demodulator's
     // counters and power sums are then updated as demod_2400.c:175,304-310,329-337,355-362,378-382 do.
@@ -162,6 +165,7 @@ private:
     CrcTables crc_;
     IcaoFilter filter_;
     rsb_stats stats_;
+    uint32_t block_len_ = kBlock;
 };
 
 }  // namespace rsb

@@ -5,6 +5,7 @@
 
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "ctx.hpp"
 
@@ -25,7 +26,11 @@ struct rsb_stream {
     uint64_t filled = 0;        // samples staged in h_stage[cur]
     unsigned in_flight = 0;     // batches submitted and not collected
     bool ended = false;         // a short block was pushed
-    uint64_t bladerf_next = 0;  // rsb_stream_push_bladerf: the hardware timestamp the next sub-block should carry (0 = none seen yet)
+    // rsb_stream_push_bladerf (the state of handle_bladerf_samples, sdr_bladerf.c:289-290, 322-327):
+    uint64_t bladerf_next = 0;  // nextTimestamp: the hardware timestamp the next sub-block should carry (0 = none seen yet)
+    bool bladerf = false;       // the stream is fed bladeRF buffers
+    bool reanchor = false;      // the last buffer was short: the next one starts a new run of blocks whatever its timestamp
+    std::vector<uint8_t> tail;  // the 326 samples behind the last published buffer's data (raw IQ): the next buffer's overlap (:323-324)
 };
 
 namespace {
@@ -69,7 +74,7 @@ int submit_staged(rsb_stream *st) {
 
 // append samples to the staging buffer, submitting every time it is full (any count: sub-blocks of a framed transfer)
 int stage_samples(rsb_stream *st, const uint8_t *src, uint64_t n) {
-    const uint64_t cap = (uint64_t)st->blocks * kBlock;
+    const uint64_t cap = (uint64_t)st->blocks * st->c->block_len;
     while (n) {
         if (st->filled >= cap) {  // an earlier submit failed and left the buffer full
             st->c->err = "rsb_stream: the staging buffer is full (an earlier push failed)";
@@ -122,8 +127,8 @@ int rsb_stream_open(rsb_ctx *c, uint32_t blocks_per_batch, rsb_stream_sink sink,
         c->err = "rsb_stream_open: a batch is pending";
         return RSB_ESTATE;
     }
-    if ((uint64_t)blocks_per_batch * kBlock > c->cfg.max_batch_samples) {
-        c->err = "rsb_stream_open: blocks_per_batch * 131072 exceeds rsb_config.max_batch_samples";
+    if ((uint64_t)blocks_per_batch * c->block_len > c->cfg.max_batch_samples) {
+        c->err = "rsb_stream_open: blocks_per_batch blocks (131072 samples, or rsb_config.block_samples) exceed rsb_config.max_batch_samples";
         return RSB_EINVAL;
     }
     rsb_stream *st = new (std::nothrow) rsb_stream;
@@ -133,9 +138,9 @@ int rsb_stream_open(rsb_ctx *c, uint32_t blocks_per_batch, rsb_stream_sink sink,
     st->user = user;
     st->blocks = blocks_per_batch;
     st->bps = (c->cfg.input_format == RSB_UC8) ? 2 : 4;
-    const size_t bytes = (size_t)blocks_per_batch * kBlock * st->bps;
+    const size_t bytes = (size_t)blocks_per_batch * c->block_len * st->bps;
     // at most one message per 64 samples: a 56-bit frame and its preamble span 154 samples, a Mode A/C reply skips 69
-    st->out_cap = (size_t)blocks_per_batch * (kBlock / 64);
+    st->out_cap = (size_t)blocks_per_batch * (c->block_len / 64);
     hipError_t e = hipSetDevice(c->cfg.device);
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
         e = hipHostMalloc((void **)&st->h_stage[k], bytes, hipHostMallocDefault);
@@ -153,16 +158,17 @@ int rsb_stream_open(rsb_ctx *c, uint32_t blocks_per_batch, rsb_stream_sink sink,
 }
 
 int rsb_stream_push(rsb_stream *st, const void *iq_host, uint32_t nsamples, uint64_t dropped_before) {
-    if (!st || (!iq_host && nsamples) || nsamples > kBlock) return RSB_EINVAL;
+    if (!st || (!iq_host && nsamples) || nsamples > st->c->block_len) return RSB_EINVAL;
     rsb_ctx *c = st->c;
+    const uint32_t L = c->block_len;
     if (st->ended) {
         c->err = "rsb_stream_push: the stream ended with a short block";
         return RSB_ESTATE;
     }
     ST_TRY(st, hipSetDevice(c->cfg.device));
     if (dropped_before) {
-        if (dropped_before % kBlock != 0) {
-            c->err = "rsb_stream_push: only whole 131072-sample blocks can be dropped";
+        if (dropped_before % L != 0) {
+            c->err = "rsb_stream_push: only whole blocks can be dropped";
             return RSB_EINVAL;
         }
         int rc = submit_staged(st);
@@ -172,20 +178,28 @@ int rsb_stream_push(rsb_stream *st, const void *iq_host, uint32_t nsamples, uint
         if (rc != RSB_OK) return rc;
     }
     if (!nsamples) return RSB_OK;
-    if (st->filled + nsamples > (uint64_t)st->blocks * kBlock) {  // an earlier submit failed and left the buffer full
+    if (st->filled + nsamples > (uint64_t)st->blocks * L) {  // an earlier submit failed and left the buffer full
         c->err = "rsb_stream_push: the staging buffer is full (an earlier push failed)";
         return RSB_ESTATE;
     }
     std::memcpy(st->h_stage[st->cur] + (size_t)st->filled * st->bps, iq_host, (size_t)nsamples * st->bps);
     st->filled += nsamples;
-    if (nsamples < kBlock) {
+    if (nsamples < L) {
         st->ended = true;
         const int rc = submit_staged(st);
         return rc == RSB_OK ? drain(st) : rc;
     }
-    return st->filled == (uint64_t)st->blocks * kBlock ? submit_staged(st) : RSB_OK;
+    return st->filled == (uint64_t)st->blocks * L ? submit_staged(st) : RSB_OK;
 }
 
+// handle_bladerf_samples (sdr_bladerf.c:283-422) on one transfer buffer, sub-block by sub-block, with the reference's own state:
+// nextTimestamp starts at 0 ("none", :289, 366), so the first sub-block ever is taken unchecked and the second one -- unless the
+// hardware counter started at 0 -- is a mismatch that restarts the buffer there; a mismatch drops what the buffer held so far
+// (:370-373) and the buffer's sampleTimestamp becomes the new timestamp's (:382); the published mag_buf holds the sub-blocks from the
+// last restart on; its overlap is the 326 samples behind the previous published buffer's data whatever happened in between
+// (:323-324: outbuf->dropped is 0 for every slot this driver publishes, :413).  A published buffer is one block of the context:
+// full ones are staged and leave in batches; a short one (restart, wrong magic) ends the run of blocks -- it leaves as the last
+// block of a ragged batch, and the next buffer starts a new run (rsb_seek to its position, carry = that overlap).
 int rsb_stream_push_bladerf(rsb_stream *st, const void *buf, size_t bytes, uint32_t block_size, uint32_t decimation, uint32_t *overruns) {
     if (!st || !buf || block_size <= 16 || (block_size - 16) % 4 != 0 || !decimation) return RSB_EINVAL;
     rsb_ctx *c = st->c;
@@ -193,61 +207,71 @@ int rsb_stream_push_bladerf(rsb_stream *st, const void *buf, size_t bytes, uint3
         c->err = "rsb_stream_push_bladerf: the context must take 4-byte samples (SC16Q11 is what the bladeRF delivers)";
         return RSB_EINVAL;
     }
+    const uint32_t per_block = (block_size - 16) / 4, L = c->block_len;  // sdr_bladerf.c:335
+    const size_t nsub = bytes / block_size;
+    if ((uint64_t)nsub * per_block != L || (c->run_ac && c->mean_sub != per_block)) {
+        c->err = "rsb_stream_push_bladerf: rsb_config.block_samples must be the samples of one transfer buffer (524288 / block_size sub-blocks of "
+                 "(block_size - 16) / 4 samples: 129024 or 130048) and, with mode_ac, mean_sub_samples those of one sub-block";
+        return RSB_EINVAL;
+    }
     if (st->ended) {
         c->err = "rsb_stream_push_bladerf: the stream has ended";
         return RSB_ESTATE;
     }
     ST_TRY(st, hipSetDevice(c->cfg.device));
+    st->bladerf = true;
+    if (st->tail.empty()) st->tail.assign((size_t)kTrailing * 4, 0);  // the ring is calloc'ed (readsb.c:198-207): zeros before the first buffer
     const uint8_t *p = (const uint8_t *)buf;
-    const uint32_t per_block = (block_size - 16) / 4;  // sdr_bladerf.c:335
     auto rd32 = [](const uint8_t *q) { return (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24; };
-    // Pass 1 over the headers (sdr_bladerf.c:339-378): a wrong magic ends the buffer; a timestamp that is not the expected one
-    // restarts the buffer THERE -- the reference throws away what it had converted of this buffer so far (:370-373).
-    size_t nblocks = 0, first_kept = 0;
-    uint64_t expect = st->bladerf_next, restart_ts = 0;
-    bool restarted = false;
+    size_t first_kept = 0, nblocks = 0;  // the published buffer = sub-blocks [first_kept, nblocks)
+    uint64_t next = st->bladerf_next, seg_ts = 0;
     uint32_t nover = 0;
     for (size_t off = 0; off + block_size <= bytes; off += block_size, ++nblocks) {
         const uint8_t *h = p + off;
-        if (rd32(h) != 0x12344321u) break;
+        if (rd32(h) != 0x12344321u) break;  // :347-353
         const uint64_t ts = (uint64_t)rd32(h + 4) | (uint64_t)rd32(h + 8) << 32;
         if (rd32(h + 12) & 1u) ++nover;  // BLADERF_META_STATUS_OVERRUN
-        if (expect && ts != expect) {
-            restarted = true;
-            restart_ts = ts;
+        if (next && next != ts) {        // :366-375, backwards as well as forwards
             first_kept = nblocks;
+            next = ts;
         }
-        expect = ts + (uint64_t)per_block * decimation;
+        if (nblocks == first_kept) seg_ts = next;  // :380-383
+        next += (uint64_t)per_block * decimation;  // :391
     }
     if (overruns) *overruns = nover;
-    if (!nblocks) return RSB_OK;
-    if (!st->bladerf_next) {  // first buffer: the stream's sample 0 is this buffer's first sample, whatever its hardware timestamp
-        st->bladerf_next = ((uint64_t)rd32(p + 4) | (uint64_t)rd32(p + 8) << 32);
-    }
-    if (restarted) {
-        // Samples were lost: the stream position jumps as the hardware timestamp did (message timestamps stay those of the
-        // reference, sampleTimestamp = timestamp * 12e6 / rate / decimation, :382) and decoding starts from a zero carry.  The
-        // library's positions are whole blocks, so it seeks to the block the new position lies in and feeds zeros up to it.
-        if (restart_ts < st->bladerf_next) {
-            c->err = "rsb_stream_push_bladerf: the hardware timestamp went backwards";
-            return RSB_EINVAL;
-        }
-        int rc = submit_staged(st);
+    st->bladerf_next = next;
+    if (nblocks == first_kept) return RSB_OK;  // nothing converted: nothing published (:398)
+    const uint64_t seg_len = (uint64_t)(nblocks - first_kept) * per_block;
+    // sampleTimestamp = nextTimestamp * 12e6 / sample_rate / decimation (:382) = 5 x the position in samples (hardware timestamps
+    // that are not multiples of the decimation would land between two samples: the position is rounded down)
+    const uint64_t pos = seg_ts / decimation;
+    int rc;
+    if (st->reanchor || pos != c->submit_pos + st->filled) {
+        rc = submit_staged(st);
         if (rc == RSB_OK) rc = drain(st);
         if (rc != RSB_OK) return rc;
-        const uint64_t lost = (restart_ts - st->bladerf_next) / decimation;  // samples between what was staged and the sub-block kept first
-        const uint64_t pos = c->submit_pos + lost;                          // (whatever this buffer held before that sub-block is dropped, as in the reference)
-        rc = rsb_seek(c, pos / kBlock * kBlock, nullptr, 0);
+        rc = rsb_seek(c, pos, st->tail.data(), 0);
         if (rc != RSB_OK) return rc;
-        rc = stage_samples(st, nullptr, pos % kBlock);
-        if (rc != RSB_OK) return rc;
-        st->bladerf_next = restart_ts;
+        st->reanchor = false;
     }
     for (size_t k = first_kept; k < nblocks; ++k) {
-        const int rc = stage_samples(st, p + k * (size_t)block_size + 16, per_block);
+        rc = stage_samples(st, p + k * (size_t)block_size + 16, per_block);
         if (rc != RSB_OK) return rc;
     }
-    st->bladerf_next += (uint64_t)(nblocks - first_kept) * per_block * decimation;
+    // the next buffer's overlap: the last 326 samples of (this buffer's overlap ++ its data)
+    {
+        const size_t tb = st->tail.size();
+        std::vector<uint8_t> joined(st->tail);
+        for (size_t k = first_kept; k < nblocks; ++k)
+            joined.insert(joined.end(), p + k * (size_t)block_size + 16, p + k * (size_t)block_size + 16 + (size_t)per_block * 4);
+        std::memcpy(st->tail.data(), joined.data() + joined.size() - tb, tb);
+    }
+    if (seg_len < L) {  // a short buffer: the last block of this run
+        rc = submit_staged(st);
+        if (rc == RSB_OK) rc = drain(st);
+        if (rc != RSB_OK) return rc;
+        st->reanchor = true;
+    }
     return RSB_OK;
 }
 
@@ -255,7 +279,7 @@ int rsb_stream_push_bladerf(rsb_stream *st, const void *buf, size_t bytes, uint3
 // that is not a whole number of blocks would end the recording); the rest moves to the front of the other staging buffer
 static int flush_impl(rsb_stream *st, bool everything) {
     ST_TRY(st, hipSetDevice(st->c->cfg.device));
-    const uint64_t whole = st->filled / kBlock * kBlock, rest = everything ? 0 : st->filled - whole;
+    const uint64_t whole = st->filled / st->c->block_len * st->c->block_len, rest = everything ? 0 : st->filled - whole;
     const uint8_t *tail = st->h_stage[st->cur] + (size_t)whole * st->bps;
     st->filled -= rest;
     int rc = submit_staged(st);  // flips st->cur (the copy that reads the old buffer does not mind our reading it too)
@@ -273,7 +297,7 @@ static int flush_impl(rsb_stream *st, bool everything) {
 
 int rsb_stream_flush(rsb_stream *st) {
     if (!st) return RSB_EINVAL;
-    return flush_impl(st, st->bladerf_next == 0);
+    return flush_impl(st, !st->bladerf);
 }
 
 int rsb_stream_close(rsb_stream *st) {

@@ -78,3 +78,80 @@ def convert_input(fmt, n):
 
 # scenarios whose reference Beast / raw byte streams are kept as fixtures (tests/golden/wire_*.npz)
 WIRE_SCENARIOS = ["cfg1_df11_df17", "mixed_fix1", "dense_fix2_ac", "sc16_ac"]
+
+
+# ---- a bladeRF transfer sequence (sdr_bladerf.c:283-422).  block_size 1024: sub-blocks of a 16-byte metadata header +
+# 252 SC16Q11 samples, 512 of them per transfer buffer (129024 samples).  The sequence exercises every branch of the handler:
+# a hardware counter that does not start at 0 (the reference then drops the first sub-block), buffers in sequence, a forward jump in
+# the middle of a buffer, a backward jump, a wrong magic value in the middle of a buffer and the jump that follows it.
+BLADERF_BLOCK_SIZE, BLADERF_PER, BLADERF_NSUB = 1024, 252, 512
+BLADERF_BUF = BLADERF_PER * BLADERF_NSUB  # 129024
+BLADERF_SCENARIO = Scenario(8 * BLADERF_BUF, seed=61, fmt="SC16Q11", frames_per_sec=4000, modeac_per_sec=400, err1_every=6)
+BLADERF_KW = dict(nfix=1, modeac=True)
+
+
+def bladerf_transfers(iq, decimation=1):
+    """-> [(first sub-block number, timestamps[512], flags[512], magic_ok[512])] per transfer buffer; sub-block k of the whole
+    sequence carries samples iq[k * 252 : (k + 1) * 252]."""
+    import numpy as np
+
+    per, nsub, d = BLADERF_PER, BLADERF_NSUB, decimation
+    step = per * d
+    out = []
+    ts = 1_000_000 * d  # the counter has been running before the stream starts
+    for b in range(8):
+        t = ts + np.arange(nsub, dtype=np.uint64) * np.uint64(step)
+        magic = np.ones(nsub, dtype=bool)
+        flags = np.zeros(nsub, dtype=np.uint32)
+        if b == 1:
+            flags[[3, 9]] = 1                       # overruns are only counted
+        if b == 3:
+            t[100:] += np.uint64(10_000 * d)        # 10000 samples lost in the middle of the buffer
+        if b == 5:
+            t -= np.uint64(300_000 * d)             # the counter went backwards (device restart)
+        if b == 6:
+            magic[300] = False                      # the rest of the buffer is skipped
+        out.append((b * nsub, t, flags, magic))
+        ts = int(t[-1]) + step
+    return out
+
+
+def bladerf_bytes(iq, transfer):
+    """one transfer buffer as the bytes libbladeRF hands to the callback (sdr_bladerf.c:339-345)"""
+    import numpy as np
+
+    first, t, flags, magic = transfer
+    nsub, per = t.size, BLADERF_PER
+    out = np.zeros((nsub, BLADERF_BLOCK_SIZE), dtype=np.uint8)
+    hdr = np.zeros(nsub, dtype=[("magic", "<u4"), ("ts", "<u8"), ("flags", "<u4")])
+    hdr["magic"] = np.where(magic, 0x12344321, 0xdeadbeef)
+    hdr["ts"] = t
+    hdr["flags"] = flags
+    out[:, :16] = hdr.view(np.uint8).reshape(nsub, 16)
+    out[:, 16:] = np.ascontiguousarray(iq[first * per:(first + nsub) * per]).view(np.uint8).reshape(nsub, per * 4)
+    return out.reshape(-1)
+
+
+def bladerf_model(transfers, decimation=1):
+    """The mag_bufs handle_bladerf_samples publishes for the sequence -- test-side restatement of sdr_bladerf.c:339-404 (the
+    handler itself needs libbladeRF and cannot be built here) -> [(first sample in iq, length, sampleTimestamp)]"""
+    per = BLADERF_PER
+    nxt = 0
+    bufs = []
+    for first, t, flags, magic in transfers:
+        length, start, stamp = 0, 0, 0
+        for k in range(t.size):
+            if not magic[k]:
+                break
+            ts = int(t[k])
+            if nxt and nxt != ts:  # :366-375
+                length = 0
+                nxt = ts
+            if length == 0:
+                stamp = int(nxt * 12e6 / 2.4e6 / decimation)  # :382
+                start = (first + k) * per
+            length += per
+            nxt += per * decimation
+        if length:
+            bufs.append((start, length, stamp))
+    return bufs

@@ -9,6 +9,8 @@ from readsb_amd.synth import Scenario, generate
 
 pytestmark = pytest.mark.gpu
 
+REPLAY = pytest.mark.parametrize("host_replay", [False, True], ids=["device_replay", "host_replay"])
+
 BLOCK = 131072
 
 
@@ -120,67 +122,66 @@ def test_sc16q11_table_context_streams_one_batch_at_a_time(built):
     assert first_mismatch(want, got.view(REC_DTYPE)) is None
 
 
-def _bladerf_frames(iq, block_size, ts0, decimation=1, flags=None):
-    """SC16Q11 samples -> the byte stream of bladeRF metadata sub-blocks (sdr_bladerf.c:335-345): magic, timestamp, flags, samples"""
-    per = (block_size - 16) // 4
-    assert iq.shape[0] % per == 0
-    nb = iq.shape[0] // per
-    out = np.zeros((nb, block_size), dtype=np.uint8)
-    hdr = np.zeros(nb, dtype=[("magic", "<u4"), ("ts", "<u8"), ("flags", "<u4")])
-    hdr["magic"] = 0x12344321
-    hdr["ts"] = ts0 + np.arange(nb, dtype=np.uint64) * np.uint64(per * decimation)
-    if flags is not None:
-        hdr["flags"] = flags
-    out[:, :16] = hdr.view(np.uint8).reshape(nb, 16)
-    out[:, 16:] = np.ascontiguousarray(iq).view(np.uint8).reshape(nb, per * 4)
-    return out.reshape(-1)
+def test_bladerf_transfer_sequence_matches_the_reference_chain(built):
+    """SURVEY 8 f3, rsb_stream_push_bladerf = handle_bladerf_samples (sdr_bladerf.c:283-422): framed transfer buffers in, the mag_buf
+    chain of the reference out -- first sub-block dropped (the counter does not start at 0), a forward jump inside a buffer, a backward
+    jump, a wrong magic inside a buffer; buffers of 129024 samples (block_samples) whose means are the averages of the 252-sample
+    sub-blocks' means (mean_sub_samples).  Compared with (a) the golden list the unmodified reference's converter and demodulators
+    produced for that chain (ref_harness demodbufs; the handler's framing logic itself needs libbladeRF: the chain is
+    tests/scenarios.py's restatement of it) and (b) the oracle."""
+    import os
 
+    from scenarios import (BLADERF_BLOCK_SIZE, BLADERF_BUF, BLADERF_KW, BLADERF_PER, BLADERF_SCENARIO, bladerf_bytes, bladerf_model,
+                           bladerf_transfers)
 
-def test_bladerf_framing_is_stripped(built):
-    """rsb_stream_push_bladerf (sdr_bladerf.c:335-394).  PARITY UNPINNED against the reference (the handler needs libbladeRF);
-    pinned here: (a) framed transfer buffers decode exactly as the oracle decodes the de-framed samples, overrun flags are
-    counted, a timer's flush in the middle only sends whole blocks; (b) a jump of the hardware timestamp drops what the buffer
-    held before it, restarts from a zero carry and moves the message timestamps by the samples lost."""
-    block_size, per = 1024, 252
-    nbuf = 131072 * 4 // block_size * per          # samples per transfer buffer: 129024
-    sc = Scenario(5 * nbuf, seed=41, fmt="SC16Q11", frames_per_sec=4000)
-    iq = generate(sc)
-    want, _ = Oracle(fmt="SC16Q11", nfix=1).run_stream(iq)
-    assert want.size > 500
-    ch = readsb_amd.Channel(fmt="SC16Q11", fix_bits=1, max_batch_samples=2 * BLOCK)
+    iq = generate(BLADERF_SCENARIO)
+    transfers = bladerf_transfers(iq)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demod_bladerf_chain.npz"))
+    gold = z["msgs"].reshape(-1).view(REC_DTYPE)
+    want, wst = Oracle(fmt="SC16Q11", nfix=BLADERF_KW["nfix"], modeac=True).run_bufs(iq, bladerf_model(transfers), sub_len=BLADERF_PER)
+    assert first_mismatch(gold, want) is None and want.size > 500
+    for blocks in (1, 3):
+        ch = readsb_amd.Channel(fmt="SC16Q11", fix_bits=BLADERF_KW["nfix"], mode_ac=True, max_batch_samples=blocks * BLADERF_BUF,
+                                block_samples=BLADERF_BUF, mean_sub_samples=BLADERF_PER)
+        st = readsb_amd.Stream(ch, blocks)
+        overruns = [st.push_bladerf(bladerf_bytes(iq, t), BLADERF_BLOCK_SIZE) for t in transfers]
+        st.close()
+        assert overruns == [0, 2, 0, 0, 0, 0, 0, 0]
+        assert first_mismatch(gold, st.messages().view(REC_DTYPE)) is None
+        stats = ch.stats()
+        assert stats["demod_modeac"] == wst["modeac"] and stats["demod_accepted"] == [wst["accepted0"], wst["accepted1"], wst["accepted2"]]
+        ch.close()
+    # a context of another geometry is refused, with the reason
+    ch = readsb_amd.Channel(fmt="SC16Q11", max_batch_samples=2 * BLOCK)
     st = readsb_amd.Stream(ch, 2)
-    ts0 = 123456789
-    flags = np.zeros(nbuf // per, dtype=np.uint32)
-    flags[[3, 9]] = 1
-    for k in range(5):
-        over = st.push_bladerf(_bladerf_frames(iq[k * nbuf:(k + 1) * nbuf], block_size, ts0 + k * nbuf, flags=flags if k == 1 else None), block_size)
-        assert over == (2 if k == 1 else 0)
-        if k == 2:
-            st.flush()
+    with pytest.raises(readsb_amd.RsbError, match="block_samples must be the samples of one transfer buffer"):
+        st.push_bladerf(bladerf_bytes(iq, transfers[0]), BLADERF_BLOCK_SIZE)
     st.close()
-    assert first_mismatch(want, st.messages().view(REC_DTYPE)) is None
-    assert ch.stats()["samples_processed"] == sc.n_samples
     ch.close()
 
-    # (b) two buffers, then a buffer whose sub-blocks 0..99 are in sequence and whose sub-block 100 comes 10000 samples late
-    a, b = iq[:2 * nbuf + 100 * per], iq[3 * nbuf:4 * nbuf]
-    lost = 10000
-    ch = readsb_amd.Channel(fmt="SC16Q11", fix_bits=1, max_batch_samples=2 * BLOCK)
-    st = readsb_amd.Stream(ch, 2)
-    st.push_bladerf(_bladerf_frames(a[:nbuf], block_size, ts0), block_size)
-    st.push_bladerf(_bladerf_frames(a[nbuf:2 * nbuf], block_size, ts0 + nbuf), block_size)
-    third = np.concatenate([_bladerf_frames(a[2 * nbuf:], block_size, ts0 + 2 * nbuf),
-                            _bladerf_frames(b[:nbuf - 100 * per], block_size, ts0 + 2 * nbuf + 100 * per + lost)])
-    st.push_bladerf(third, block_size)
-    st.close()
-    got = st.messages()
+
+@REPLAY
+def test_block_samples_through_plain_batches(host_replay, built):
+    """rsb_config.block_samples / mean_sub_samples without the stream layer: a recording submitted in batches of whole 129024-sample
+    blocks decodes as the oracle's chain of such buffers does (skip windows, Mode A/C runs and noise levels per buffer), on the device
+    replay and on the host replay."""
+    from scenarios import BLADERF_BUF, BLADERF_PER, BLADERF_SCENARIO
+
+    iq = generate(BLADERF_SCENARIO)[:5 * BLADERF_BUF + 7 * BLADERF_PER]
+    n = iq.shape[0]
+    bufs = [(p, min(BLADERF_BUF, n - p), 5 * p) for p in range(0, n, BLADERF_BUF)]
+    want, _ = Oracle(fmt="SC16Q11", nfix=2, modeac=True).run_bufs(iq, bufs, sub_len=BLADERF_PER)
+    ch = readsb_amd.Channel(fmt="SC16Q11", fix_bits=2, mode_ac=True, host_replay=host_replay, max_batch_samples=2 * BLADERF_BUF,
+                            block_samples=BLADERF_BUF, mean_sub_samples=BLADERF_PER)
+    got = ch.process_stream_host(iq, 2, block=BLADERF_BUF)
     ch.close()
-    pos_b = 2 * nbuf + 100 * per + lost          # stream position of b's first sample
-    ref = readsb_amd.Channel(fmt="SC16Q11", fix_bits=1, max_batch_samples=8 * BLOCK)
-    part_a = ref.process_host(a[:2 * nbuf])      # the third buffer's first 100 sub-blocks are dropped with the jump
-    ref.seek(pos_b // BLOCK * BLOCK, None)
-    padded = np.concatenate([np.zeros((pos_b % BLOCK, 2), dtype=iq.dtype), b[:nbuf - 100 * per]])
-    part_b = ref.process_host(padded)
-    ref.close()
-    assert part_b.size > 50 and int(part_b["ts"].min()) >= 5 * pos_b
-    assert first_mismatch(np.concatenate([part_a, part_b]).view(REC_DTYPE), got.view(REC_DTYPE)) is None
+    assert want.size > 300 and first_mismatch(want, got.view(REC_DTYPE)) is None
+
+
+def test_block_geometry_is_validated(built, capfd):
+    for kw in (dict(block_samples=129025), dict(block_samples=2048), dict(block_samples=129024, dc_filter=True),
+               dict(block_samples=129024, mean_sub_samples=250), dict(fmt="UC8", block_samples=129024, mean_sub_samples=252)):
+        kw.setdefault("fmt", "SC16Q11")
+        with pytest.raises(readsb_amd.RsbError):
+            readsb_amd.Channel(**kw)
+    assert "block_samples must be a multiple of 8" in capfd.readouterr().err

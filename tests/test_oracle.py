@@ -190,3 +190,24 @@ def test_oracle_sc16q11_table_build_matches_the_reference_built_that_way(built):
         got, stats = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"], q11_table_bits=kw["q11_table_bits"]).run_stream(iq)
         assert first_mismatch(want, got) is None
         assert stats == want_stats
+
+
+def test_oracle_bladerf_buffer_chain_matches_golden(built):
+    """mag_bufs of a bladeRF transfer sequence (129024-sample buffers and shorter ones after timestamp jumps / a wrong
+    magic, converter per 252-sample sub-block, means averaged, overlap always from the buffer before: sdr_bladerf.c:322-404).  The
+    fixture is the unmodified reference's converter + demodulators run on that chain by oracle/_ref/ref_harness demodbufs."""
+    from scenarios import BLADERF_KW, BLADERF_PER, BLADERF_SCENARIO, bladerf_model, bladerf_transfers
+
+    iq = generate(BLADERF_SCENARIO)
+    z = np.load(os.path.join(GOLD, "demod_bladerf_chain.npz"))
+    assert iq_sha256(iq) == bytes(z["iq_sha256"]).hex()
+    bufs = bladerf_model(bladerf_transfers(iq))
+    assert np.array_equal(np.array(bufs, dtype=np.uint64), z["bufs"])
+    assert len(bufs) == 8 and sorted({b[1] for b in bufs}) == [75600, 103824, 128772, 129024]
+    want = z["msgs"].reshape(-1).view(REC_DTYPE)
+    got, stats = Oracle(fmt="SC16Q11", nfix=BLADERF_KW["nfix"], modeac=BLADERF_KW["modeac"]).run_bufs(iq, bufs, sub_len=BLADERF_PER)
+    assert first_mismatch(want, got) is None
+    assert stats == dict(zip(STAT_NAMES, (int(x) for x in z["stats"])))
+    # the geometry matters: the same samples in 131072-sample blocks decode differently
+    plain, _ = Oracle(fmt="SC16Q11", nfix=BLADERF_KW["nfix"], modeac=BLADERF_KW["modeac"]).run_stream(iq)
+    assert first_mismatch(plain, got) is not None
