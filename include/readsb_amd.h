@@ -311,6 +311,77 @@ int rsb_stream_push_bladerf(rsb_stream *st, const void *buf, size_t bytes, uint3
 int rsb_stream_flush(rsb_stream *st);
 int rsb_stream_close(rsb_stream *st);   /* flush, then free the stream (not the context) */
 
+/* ---- the rest of decodeModesMessage on the device ------------------------------ */
+
+/* What decodeModesMessage (mode_s.c:557-716) and decodeExtendedSquitter (mode_s.c:736-1474) make of an accepted message, and
+ * decodeModeAMessage (mode_ac.c:165-199) of a Mode A/C reply: every field of struct modesMessage (readsb.h:421-635) in the
+ * reference's own x86-64 layout, 416 bytes, so that a caller copies the record over its struct modesMessage and hands it to
+ * useModesMessage (integration/gpu_path.c does; its _Static_asserts hold the offsets against the reference's header).  Bit
+ * fields are given as the 32-bit words they occupy (gcc allocates them from bit 0 up, in declaration order).
+ * Left for the caller: sysTimestampMsg (wall clock, demod_2400.c:323), verbatim[] (only kept with Modes.net_verbatim,
+ * mode_s.c:427-430), decodeCommB for DF20/21 (comm_b.c: the BDS heuristics, out of scope -- MB[] is filled), and the tracker's
+ * fields (reduce_forward, cpr_decoded ...).  msg[] holds the first msgbits / 8 bytes, the rest is zero (the reference leaves stale
+ * stack bytes there).  The records are read and written as 32-bit words: msgs_dev and out_dev must be 4-byte aligned.  Mode A/C: the reference zeroes its struct once per block, not per message (demod_2400.c:482), so an altitude
+ * decoded for one reply stays in the struct for the later replies of the same block that decode none: reproduced. */
+typedef struct rsb_decoded {
+    uint64_t timestampMsg;             /*   0 */
+    uint64_t sysTimestampMsg;          /*   8  0: the caller's */
+    uint8_t msg[14];                   /*  16 */
+    uint8_t verbatim[14];              /*  30  0: the caller's (Mode A/C: msg[0..1], mode_ac.c:172-173) */
+    int32_t msgbits, msgtype;          /*  44  48 */
+    uint32_t crc;                      /*  52 */
+    int32_t correctedbits;             /*  56 */
+    uint32_t addr;                     /*  60  with MODES_NON_ICAO_ADDRESS where the extended squitter says so */
+    int32_t addrtype, remote, score, sbs_in, reduce_forward, source; /* 64 68 72 76 80 84 */
+    double signalLevel;                /*  88 */
+    uint32_t IID, AA, AC, CA, CC, CF, DR, FS, ID, KE, ND, RI, SL, UM, VS, metype, mesub; /* 96 .. 160 */
+    uint8_t MB[7], MD[10], ME[7], MV[7];  /* 164 171 181 188 */
+    uint8_t valid_bits[5];             /* 195  the one-bit members of readsb.h:466-492 in declaration order (gcc starts them in the byte behind
+                                        *      MV[]): member k is bit k % 8 of valid_bits[k / 8] -- altitude_baro_valid 0, altitude_geom_valid 1,
+                                        *      track_valid 2, track_rate_valid 3, heading_valid 4, roll_valid 5, gs_valid 6, ias_valid 7, tas_valid 8,
+                                        *      mach_valid 9, baro_rate_valid 10, geom_rate_valid 11, squawk_valid 12, callsign_valid 13, cpr_valid 14,
+                                        *      cpr_odd 15, cpr_decoded 16, cpr_relative 17, category_valid 18, geom_delta_valid 19, from_mlat 20,
+                                        *      from_tisb 21, spi_valid 22, spi 23, alert_valid 24, alert 25, emergency_valid 26 */
+    int32_t altitude_baro, altitude_baro_unit, altitude_geom, altitude_geom_unit, geom_delta; /* 200 .. 216 */
+    float heading;                     /* 220 */
+    int32_t heading_type;              /* 224 */
+    float track_rate, roll;            /* 228 232 */
+    float gs_v0, gs_v2, gs_selected;   /* 236 240 244 */
+    uint32_t ias, tas;                 /* 248 252 */
+    double mach;                       /* 256 */
+    int32_t baro_rate, geom_rate;      /* 264 268 */
+    uint32_t squawk;                   /* 272 */
+    char callsign[16];                 /* 276 */
+    uint32_t category;                 /* 292 */
+    int32_t emergency, cpr_type;       /* 296 300 */
+    uint32_t cpr_lat, cpr_lon, cpr_nucp; /* 304 308 312 */
+    int32_t airground;                 /* 316 */
+    double decoded_lat, decoded_lon;   /* 320 328 */
+    uint32_t decoded_nic, decoded_rc;  /* 336 340 */
+    int32_t commb_format;              /* 344 */
+    uint32_t accuracy_bits;            /* 348  nic_a_valid = bit 0 ... sda = bits 23-24 (readsb.h:551-572) */
+    int32_t accuracy_sil_type;         /* 352 */
+    int32_t opstatus_sil_type, opstatus_tah, opstatus_hrd, opstatus_track_angle; /* 356 .. 368 */
+    uint32_t opstatus_cc_lw, opstatus_cc_antenna_offset; /* 372 376 */
+    uint32_t opstatus_bits;            /* 380  valid = bit 0, version = bits 1-3 ... cc_lw_valid = bit 18 (readsb.h:592-609) */
+    uint32_t nav_fms_altitude, nav_mcp_altitude; /* 384 388 */
+    float nav_qnh, nav_heading;        /* 392 396 */
+    uint32_t nav_bits;                 /* 400  heading_valid = bit 0 ... modes_valid = bit 4 (readsb.h:623-627) */
+    int32_t nav_heading_type, nav_altitude_source, nav_modes; /* 404 408 412 */
+} rsb_decoded;
+#define RSB_DECODED_BYTES 416
+
+/* n message records on the device -> n rsb_decoded on the device, asynchronously on `stream` (one thread per message; no PCIe).
+ * batch_pos / block_samples: the stream position of the batch the records came from and the context's block length -- they only
+ * serve the Mode A/C quirk above (0, 0: every Mode A/C reply decoded on its own).  *cpr_filtered_dev (optional, device memory) is
+ * raised once per airborne position that mode_s.c:991-998 refuses (Modes.stats_current.cpr_filtered). */
+int rsb_decode_fields_device(rsb_ctx *ctx, const rsb_message *msgs_dev, size_t n, uint64_t batch_pos, uint32_t block_samples, rsb_decoded *out_dev,
+                             uint32_t *cpr_filtered_dev, void *stream);
+/* The same from and to host memory (blocking: upload, kernel, download). */
+int rsb_decode_fields(rsb_ctx *ctx, const rsb_message *msgs, size_t n, uint64_t batch_pos, rsb_decoded *out);
+/* rsb_collect + the decoded structs of the same messages: out[i] and dec[i] belong together (dec may be NULL: plain rsb_collect) */
+int rsb_collect_decoded(rsb_ctx *ctx, rsb_message *out, rsb_decoded *dec, size_t cap, size_t *n_out);
+
 /* ---- wire formats of the message list ---------------------------------------- */
 
 /* What modesQueueOutput (net_io.c:1249-1276) writes for Beast-binary clients (modesSendBeastOutput, :760-826:

@@ -1081,3 +1081,18 @@ size_t orc_forward_order(const orc_msg *m, size_t n, uint32_t *idx) {
     free(first);
     return k;
 }
+
+/* ---- field decode: the floating-point members of decodeESAirborneVelocity ---- */
+
+/* mode_s.c:831 (sqrtf of a double expression narrowed to float) and :835-839 (atan2 in double, degrees, narrowed to float,
+ * negative angles moved up by 360 in float) */
+void orc_es_velocity(const int32_t *ew, const int32_t *ns, size_t n, float *gs, float *track) {
+    for (size_t i = 0; i < n; ++i) {
+        int ew_vel = ew[i], ns_vel = ns[i];
+        gs[i] = sqrtf((ns_vel * ns_vel) + (ew_vel * ew_vel) + 0.5);
+        float ground_track = atan2(ew_vel, ns_vel) * 180.0 / M_PI;
+        if (ground_track < 0)
+            ground_track += 360;
+        track[i] = ground_track;
+    }
+}

@@ -118,6 +118,12 @@ size_t orc_raw_encode(const orc_msg *m, size_t n, int mlat, uint8_t *out, size_t
  * modesQueueOutput, in order (a first message goes out just before the second); returns their number (<= 2n) */
 size_t orc_forward_order(const orc_msg *m, size_t n, uint32_t *idx);
 
+/* ---- field decode ---- */
+/* The two floating-point members of decodeESAirborneVelocity (mode_s.c:826-842) for n pairs of signed velocity components:
+ * gs = sqrtf(ns^2 + ew^2 + 0.5) and the ground track atan2(ew, ns) in degrees, 0 .. 360, through this host's libm -- the same glibc
+ * the reference links.  (Everything else of the field decode is integer work and is checked against the reference's own structs.) */
+void orc_es_velocity(const int32_t *ew, const int32_t *ns, size_t n, float *gs, float *track);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,7 @@ def _lib():
     lib.orc_raw_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
     lib.orc_forward_order.restype = C.c_size_t
     lib.orc_forward_order.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.orc_es_velocity.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     return lib
 
 
@@ -211,8 +212,20 @@ def forward_order(recs: np.ndarray) -> np.ndarray:
     return idx[:n].copy()
 
 
+def es_velocity(ew: np.ndarray, ns: np.ndarray):
+    """(gs, ground track) of decodeESAirborneVelocity (mode_s.c:826-842) for signed velocity components, through this host's libm"""
+    ew = np.ascontiguousarray(ew, dtype=np.int32)
+    ns = np.ascontiguousarray(ns, dtype=np.int32)
+    gs, track = np.zeros(ew.size, dtype=np.float32), np.zeros(ew.size, dtype=np.float32)
+    _lib().orc_es_velocity(ew.ctypes.data, ns.ctypes.data, ew.size, gs.ctypes.data, track.ctypes.data)
+    return gs, track
+
+
 REF_GPU_BIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "ref_harness_gpu")
 REF_T8_BIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "ref_harness_t8")  # reference built with -DSC16Q11_TABLE_BITS=8
+
+
+MM_BYTES = 416  # sizeof(struct modesMessage), readsb.h:421-635 on x86-64
 
 
 class RefHarness:
@@ -223,13 +236,14 @@ class RefHarness:
         return os.access(REF_BIN, os.X_OK)
 
     @staticmethod
-    def demod(iq: np.ndarray, fmt="UC8", nfix=1, modeac=False, dc_filter=False, verbatim=False, binary=None):
+    def demod(iq: np.ndarray, fmt="UC8", nfix=1, modeac=False, dc_filter=False, verbatim=False, binary=None, full=False):
         """verbatim=True: also (msg, verbatim) of every message, with Modes.net_verbatim set (mode_s.c:427-430).
+        full=True: also every message's whole struct modesMessage (n x 416 bytes) as useModesMessage receives it, decodeCommB skipped.
         binary: REF_GPU_BIN = the same harness linked against integration/gpu_path.c + libreadsb_amd.so instead of demod_2400.o / convert.o"""
         with tempfile.TemporaryDirectory() as d:
             fin, fout = os.path.join(d, "in.iq"), os.path.join(d, "out.bin")
             iq_bytes(iq).tofile(fin)
-            subprocess.run([binary or REF_BIN, "demodv" if verbatim else "demod", fmt, str(int(nfix)), str(int(modeac)), str(int(dc_filter)), fin, fout],
+            subprocess.run([binary or REF_BIN, "demodfull" if full else "demodv" if verbatim else "demod", fmt, str(int(nfix)), str(int(modeac)), str(int(dc_filter)), fin, fout],
                            check=True, stderr=None if binary else subprocess.DEVNULL)
             raw = np.fromfile(fout, dtype=np.uint8)
         hdr = raw[:64].view("<u8")
@@ -238,8 +252,29 @@ class RefHarness:
         st = dict(zip(STAT_NAMES, (int(x) for x in hdr[1:8])))
         if verbatim:
             return recs.copy(), st, raw[64 + 56 * n:].reshape(n, 2, 14).copy()
+        if full:
+            return recs.copy(), st, raw[64 + 56 * n:].reshape(n, MM_BYTES).copy()
         assert raw.size == 64 + 56 * n
         return recs.copy(), st
+
+    @staticmethod
+    def decodemsgs(frames: np.ndarray, addrs=()):
+        """The reference's decodeModesMessage (mode_s.c:424-734, decodeCommB skipped) on frames[n][14], the ICAO filter holding
+        addrs -> (result[n], struct modesMessage images [n][416], stats_current.cpr_filtered)"""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, 14)
+        addrs = np.ascontiguousarray(addrs, dtype="<u4")
+        with tempfile.TemporaryDirectory() as d:
+            fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+            with open(fin, "wb") as f:
+                f.write(np.array([addrs.size, frames.shape[0]], dtype="<u4").tobytes())
+                f.write(addrs.tobytes())
+                f.write(frames.tobytes())
+            subprocess.run([REF_BIN, "decodemsgs", fin, fout], check=True)
+            raw = np.fromfile(fout, dtype=np.uint8)
+        n = frames.shape[0]
+        assert raw.size == n * (4 + MM_BYTES) + 4
+        body = raw[:n * (4 + MM_BYTES)].reshape(n, 4 + MM_BYTES)
+        return body[:, :4].copy().view("<i4").reshape(n), body[:, 4:].copy(), int(raw[-4:].view("<u4")[0])
 
     @staticmethod
     def demodbufs(iq: np.ndarray, bufs, sub_len=0, fmt="UC8", nfix=1, modeac=False, dc_filter=False):

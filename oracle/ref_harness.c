@@ -17,6 +17,14 @@
  *   demodv  (same arguments)                                       the same with Modes.net_verbatim set; behind the records: msg[14] as
  *                                                                 delivered and verbatim[14] (mode_s.c:427-430) of every message
  *
+ *   demodfull (same arguments as demod)                            behind the records: the whole struct modesMessage (416 bytes) of every message as
+ *                                                                 useModesMessage receives it, WITHOUT decodeCommB's work (the harness is linked
+ *                                                                 with -Wl,--wrap=decodeCommB and skips the call in this mode and in decodemsgs: comm_b.c
+ *                                                                 is outside SURVEY.md section 8; every other mode calls the real one)
+ *   decodemsgs <in.bin> <out.bin>                                  decodeModesMessage (mode_s.c:424-734) on frames from a file: in = {u32 naddr, u32 nframes,
+ *                                                                 u32 addr[naddr] (icaoFilterAdd'ed first), u8 frame[nframes][14]}; out = per frame
+ *                                                                 {i32 result, struct modesMessage}, then u32 stats_current.cpr_filtered
+ *
  *   demodbufs <fmt> <nfix> <modeac> <dcfilter> <sublen> <in.iq> <bufs.bin> <out.bin>
  *                                                                 a chain of mag_bufs of the caller's geometry, as a hardware driver
  *                                                                 builds it (sdr_bladerf.c:322-404 without the USB framing): bufs.bin =
@@ -63,6 +71,15 @@ static size_t nrecs, caprecs;
 static int capture = 1;
 static uint8_t (*verb)[2][14]; /* demodv: msg, verbatim of every captured message */
 static int capture_verbatim;
+static struct modesMessage *full; /* demodfull: the whole struct of every captured message */
+static int capture_full;
+static int skip_commb;
+
+void __real_decodeCommB(struct modesMessage *mm);
+void __wrap_decodeCommB(struct modesMessage *mm) {
+    if (!skip_commb)
+        __real_decodeCommB(mm);
+}
 
 /* wire capture: both writers point at a service with one pretend connection and no clients; the
  * harness drains their shared buffers after every message, so flushWrites never runs */
@@ -97,7 +114,10 @@ void __wrap_useModesMessage(struct modesMessage *mm) {
         caprecs = caprecs ? caprecs * 2 : 4096;
         recs = realloc(recs, caprecs * sizeof (*recs));
         if (capture_verbatim) verb = realloc(verb, caprecs * sizeof (*verb));
+        if (capture_full) full = realloc(full, caprecs * sizeof (*full));
     }
+    if (capture_full)
+        full[nrecs] = *mm;
     if (capture_verbatim) {
         memcpy(verb[nrecs][0], mm->msg, 14);
         memcpy(verb[nrecs][1], mm->verbatim, 14);
@@ -291,6 +311,7 @@ static int cmd_demod(int argc, char **argv) {
     uint8_t *iq = slurp(argv[6], &nbytes);
     init_modes(nfix, modeac, dc);
     capture_verbatim = Modes.net_verbatim = !strcmp(argv[1], "demodv");
+    capture_full = skip_commb = !strcmp(argv[1], "demodfull");
     run_stream(fmt, iq, nbytes, modeac);
     FILE *f = fopen(argv[7], "wb");
     if (!f) { perror(argv[7]); return 2; }
@@ -305,6 +326,41 @@ static int cmd_demod(int argc, char **argv) {
     fwrite(hdr, sizeof (hdr), 1, f);
     fwrite(recs, sizeof (*recs), nrecs, f);
     if (capture_verbatim) fwrite(verb, sizeof (*verb), nrecs, f);
+    if (capture_full) fwrite(full, sizeof (*full), nrecs, f);
+    fclose(f);
+    return 0;
+}
+
+/* the reference's decodeModesMessage on frames from a file */
+static int cmd_decodemsgs(int argc, char **argv) {
+    if (argc != 4) return 2;
+    size_t nbytes;
+    uint8_t *in = slurp(argv[2], &nbytes);
+    uint32_t naddr, nframes;
+    memcpy(&naddr, in, 4);
+    memcpy(&nframes, in + 4, 4);
+    if (nbytes != 8 + 4 * (size_t) naddr + 14 * (size_t) nframes) return 2;
+    init_modes(1, 0, 0);
+    skip_commb = 1;
+    for (uint32_t k = 0; k < naddr; ++k) {
+        uint32_t a;
+        memcpy(&a, in + 8 + 4 * (size_t) k, 4);
+        icaoFilterAdd(a);
+    }
+    const uint8_t *frames = in + 8 + 4 * (size_t) naddr;
+    FILE *f = fopen(argv[3], "wb");
+    if (!f) { perror(argv[3]); return 2; }
+    for (uint32_t k = 0; k < nframes; ++k) {
+        struct modesMessage mm;
+        unsigned char frame[MODES_LONG_MSG_BYTES];
+        memset(&mm, 0, sizeof (mm));
+        memcpy(frame, frames + 14 * (size_t) k, 14);
+        int32_t result = decodeModesMessage(&mm, frame);
+        fwrite(&result, 4, 1, f);
+        fwrite(&mm, sizeof (mm), 1, f);
+    }
+    uint32_t filtered = Modes.stats_current.cpr_filtered; /* mode_s.c:991-998 */
+    fwrite(&filtered, 4, 1, f);
     fclose(f);
     return 0;
 }
@@ -445,7 +501,8 @@ static int cmd_crctab(int argc, char **argv) {
 int main(int argc, char **argv) {
     int rc = 2;
     if (argc >= 2) {
-        if (!strcmp(argv[1], "demod") || !strcmp(argv[1], "demodv")) rc = cmd_demod(argc, argv);
+        if (!strcmp(argv[1], "demod") || !strcmp(argv[1], "demodv") || !strcmp(argv[1], "demodfull")) rc = cmd_demod(argc, argv);
+        else if (!strcmp(argv[1], "decodemsgs")) rc = cmd_decodemsgs(argc, argv);
         else if (!strcmp(argv[1], "demodbufs")) rc = cmd_demodbufs(argc, argv);
         else if (!strcmp(argv[1], "time")) rc = cmd_time(argc, argv);
         else if (!strcmp(argv[1], "stats")) rc = cmd_stats(argc, argv);

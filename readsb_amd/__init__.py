@@ -29,6 +29,25 @@ CAND_DTYPE = np.dtype([("g", "<u4"), ("vbytes", "u1", (5,)), ("pad", "u1"), ("ms
                        ("pow134", "<u8"), ("pow268", "<u8")])
 AC_DTYPE = np.dtype([("g", "<u4"), ("f2_clock", "<u4"), ("modeac", "<u4")])
 assert MSG_DTYPE.itemsize == 56 and CAND_DTYPE.itemsize == 96 and AC_DTYPE.itemsize == 12
+# rsb_decoded = struct modesMessage (readsb.h:421-635) in its x86-64 layout
+DECODED_DTYPE = np.dtype([
+    ("timestampMsg", "<u8"), ("sysTimestampMsg", "<u8"), ("msg", "u1", (14,)), ("verbatim", "u1", (14,)), ("msgbits", "<i4"), ("msgtype", "<i4"),
+    ("crc", "<u4"), ("correctedbits", "<i4"), ("addr", "<u4"), ("addrtype", "<i4"), ("remote", "<i4"), ("score", "<i4"), ("sbs_in", "<i4"),
+    ("reduce_forward", "<i4"), ("source", "<i4"), ("signalLevel", "<f8"),
+    ("IID", "<u4"), ("AA", "<u4"), ("AC", "<u4"), ("CA", "<u4"), ("CC", "<u4"), ("CF", "<u4"), ("DR", "<u4"), ("FS", "<u4"), ("ID", "<u4"), ("KE", "<u4"),
+    ("ND", "<u4"), ("RI", "<u4"), ("SL", "<u4"), ("UM", "<u4"), ("VS", "<u4"), ("metype", "<u4"), ("mesub", "<u4"),
+    ("MB", "u1", (7,)), ("MD", "u1", (10,)), ("ME", "u1", (7,)), ("MV", "u1", (7,)), ("valid_bits", "u1", (5,)),
+    ("altitude_baro", "<i4"), ("altitude_baro_unit", "<i4"), ("altitude_geom", "<i4"), ("altitude_geom_unit", "<i4"), ("geom_delta", "<i4"),
+    ("heading", "<f4"), ("heading_type", "<i4"), ("track_rate", "<f4"), ("roll", "<f4"), ("gs_v0", "<f4"), ("gs_v2", "<f4"), ("gs_selected", "<f4"),
+    ("ias", "<u4"), ("tas", "<u4"), ("mach", "<f8"), ("baro_rate", "<i4"), ("geom_rate", "<i4"), ("squawk", "<u4"), ("callsign", "S16"),
+    ("category", "<u4"), ("emergency", "<i4"), ("cpr_type", "<i4"), ("cpr_lat", "<u4"), ("cpr_lon", "<u4"), ("cpr_nucp", "<u4"), ("airground", "<i4"),
+    ("decoded_lat", "<f8"), ("decoded_lon", "<f8"), ("decoded_nic", "<u4"), ("decoded_rc", "<u4"), ("commb_format", "<i4"),
+    ("accuracy_bits", "<u4"), ("accuracy_sil_type", "<i4"), ("opstatus_sil_type", "<i4"), ("opstatus_tah", "<i4"), ("opstatus_hrd", "<i4"),
+    ("opstatus_track_angle", "<i4"), ("opstatus_cc_lw", "<u4"), ("opstatus_cc_antenna_offset", "<u4"), ("opstatus_bits", "<u4"),
+    ("nav_fms_altitude", "<u4"), ("nav_mcp_altitude", "<u4"), ("nav_qnh", "<f4"), ("nav_heading", "<f4"), ("nav_bits", "<u4"),
+    ("nav_heading_type", "<i4"), ("nav_altitude_source", "<i4"), ("nav_modes", "<i4"),
+])
+assert DECODED_DTYPE.itemsize == 416 and DECODED_DTYPE.fields["valid_bits"][1] == 195 and DECODED_DTYPE.fields["nav_modes"][1] == 412
 
 
 class Config(C.Structure):
@@ -103,6 +122,9 @@ SYMBOLS = {
     "rsb_stream_push_bladerf": (C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "rsb_stream_flush": (C.c_int, [_VP]),
     "rsb_stream_close": (C.c_int, [_VP]),
+    "rsb_decode_fields_device": (C.c_int, [_VP, _VP, _SZ, C.c_uint64, C.c_uint32, _VP, _VP, _VP]),
+    "rsb_decode_fields": (C.c_int, [_VP, _VP, _SZ, C.c_uint64, _VP]),
+    "rsb_collect_decoded": (C.c_int, [_VP, _VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_merge_by_timestamp": (C.c_int, [_VP, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_host_replay": (C.c_int, [C.c_int, C.c_uint64, _VP, _SZ, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
 }
@@ -279,6 +301,24 @@ class Channel:
             raise RsbError(f"rsb_collect: {n.value} messages exceed cap {cap}")
         self._check(rc, "rsb_collect")
         return out[:n.value]
+
+    def collect_decoded(self, cap: int = 1 << 16):
+        """rsb_collect_decoded -> (records, their decoded structs)"""
+        out = np.zeros(cap, dtype=MSG_DTYPE)
+        dec = np.zeros(cap, dtype=DECODED_DTYPE)
+        n = _SZ()
+        rc = self.l.rsb_collect_decoded(self.h, out.ctypes.data, dec.ctypes.data, cap, C.byref(n))
+        if rc == -4 and n.value > cap:
+            raise RsbError(f"rsb_collect_decoded: {n.value} messages exceed cap {cap}")
+        self._check(rc, "rsb_collect_decoded")
+        return out[:n.value], dec[:n.value]
+
+    def decode_fields(self, msgs: np.ndarray, batch_pos: int = 0) -> np.ndarray:
+        """rsb_decode_fields: records on the host -> struct modesMessage images on the host (through the device)"""
+        msgs = np.ascontiguousarray(msgs, dtype=MSG_DTYPE)
+        dec = np.zeros(msgs.size, dtype=DECODED_DTYPE)
+        self._check(self.l.rsb_decode_fields(self.h, msgs.ctypes.data if msgs.size else None, msgs.size, batch_pos, dec.ctypes.data if msgs.size else None), "rsb_decode_fields")
+        return dec
 
     def collect_begin(self, out: np.ndarray) -> np.ndarray:
         """rsb_collect_begin: the returned slice of `out` (pinned memory) holds the records only after collect_wait()."""

@@ -499,7 +499,7 @@ void rsb_destroy(rsb_ctx *c) {
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void *ptrs[] = {c->d_lut, c->d_radial, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
                     c->d_bitmap, c->d_summary, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
-                    c->d_magbuf, c->d_sub_means, c->d_wave_times, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge};
+                    c->d_magbuf, c->d_sub_means, c->d_wave_times, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge, c->d_dec_in, c->d_decoded};
     for (rsb_slot &b : c->slots) {
         void *sp[] = {b.d_out, b.d_blk_counts, b.d_blk_start, b.d_blk_base, b.d_new_adders, b.d_items, b.d_region_counts, b.d_region_kept, b.d_region_masks, b.d_chunk_dir, b.d_chunk_kept, b.d_chunk_group, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
         for (void *p : sp)
@@ -878,6 +878,8 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     b.pending = false;
     ++c->collected;
     c->last_n = b.pending_n;
+    c->last_list_dev = nullptr;
+    c->last_g0 = b.g0;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     // everything from here on runs on the context's own stream, behind this batch's scan and beside the next batch's
     hipStream_t s = c->replay_stream;
@@ -1039,6 +1041,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
             // straight into the caller's buffer, on the copy stream: everything the list depends on has been waited for, and the
             // replay stream is free to take the next batch's chain meanwhile
             n = nlist;
+            c->last_list_dev = list;
             const size_t ncopy = n < cap ? n : cap;
             if (list != b.d_out) HIP_TRY(c, hipStreamSynchronize(s));  // (a merged list: its kernel ran on the replay stream)
             if (ncopy) {
@@ -1215,6 +1218,62 @@ int rsb_collect(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {
     int rc = rsb_collect_wait(c);  // a copy left in flight by rsb_collect_begin
     if (rc != RSB_OK) return rc;
     return collect_impl(c, out, cap, n_out, nullptr);
+}
+
+// ---- the rest of decodeModesMessage on the device (decode_fields.hip) ----
+
+static int grow(rsb_ctx *c, void **p, size_t *cap, size_t want_bytes) {
+    if (want_bytes <= *cap) return RSB_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t bytes = want_bytes + want_bytes / 4;
+    HIP_TRY(c, hipMalloc(p, bytes));
+    *cap = bytes;
+    return RSB_OK;
+}
+
+int rsb_decode_fields_device(rsb_ctx *c, const rsb_message *msgs_dev, size_t n, uint64_t batch_pos, uint32_t block_samples, rsb_decoded *out_dev,
+                             uint32_t *cpr_filtered_dev, void *stream) {
+    if (!c || (n && (!msgs_dev || !out_dev)) || n > 0xffffffffull || (uintptr_t)msgs_dev % 4 || (uintptr_t)out_dev % 4) return RSB_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, launch_decode_fields(msgs_dev, (uint32_t)n, batch_pos, block_samples, out_dev, cpr_filtered_dev, (hipStream_t)stream));
+    return RSB_OK;
+}
+
+// records (host or device) -> c->d_decoded -> dec (host), on the copy stream
+static int decode_to_host(rsb_ctx *c, const rsb_message *msgs, bool msgs_on_device, size_t n, uint64_t batch_pos, rsb_decoded *dec) {
+    if (!n) return RSB_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t s = c->copy_stream;
+    int rc = grow(c, (void **)&c->d_decoded, &c->decoded_cap, n * sizeof(rsb_decoded));
+    if (rc != RSB_OK) return rc;
+    if (!msgs_on_device) {
+        rc = grow(c, (void **)&c->d_dec_in, &c->dec_in_cap, n * sizeof(rsb_message));
+        if (rc != RSB_OK) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->d_dec_in, msgs, n * sizeof(rsb_message), hipMemcpyHostToDevice, s));
+        msgs = c->d_dec_in;
+    }
+    HIP_TRY(c, launch_decode_fields(msgs, (uint32_t)n, batch_pos, c->block_len, c->d_decoded, nullptr, s));
+    HIP_TRY(c, hipMemcpyAsync(dec, c->d_decoded, n * sizeof(rsb_decoded), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return RSB_OK;
+}
+
+int rsb_decode_fields(rsb_ctx *c, const rsb_message *msgs, size_t n, uint64_t batch_pos, rsb_decoded *out) {
+    if (!c || (n && (!msgs || !out)) || n > 0xffffffffull) return RSB_EINVAL;
+    int rc = rsb_collect_wait(c);  // the copy stream is about to be used
+    if (rc != RSB_OK) return rc;
+    return decode_to_host(c, msgs, false, n, batch_pos, out);
+}
+
+int rsb_collect_decoded(rsb_ctx *c, rsb_message *out, rsb_decoded *dec, size_t cap, size_t *n_out) {
+    size_t n = 0;
+    int rc = rsb_collect(c, out, cap, &n);
+    if (n_out) *n_out = n;
+    if (rc != RSB_OK || !dec) return rc;
+    // the list as it lies on the device when the batch was delivered from there; otherwise (host replay, host merge) the caller's copy
+    return decode_to_host(c, c->last_list_dev ? c->last_list_dev : out, c->last_list_dev != nullptr, n, c->last_g0, dec);
 }
 
 int rsb_collect_begin(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out) {

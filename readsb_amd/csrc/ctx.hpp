@@ -111,6 +111,12 @@ struct rsb_ctx {
     uint32_t *d_wire_off = nullptr;  // rsb_collect_wire: byte offset per message (grown on demand)
     uint8_t *d_wire_out = nullptr;   // ... and the encoded stream
     size_t wire_off_cap = 0, wire_out_cap = 0;
+    // rsb_decode_fields / rsb_collect_decoded: staging for records that come from the host, the decoded structs (grown on demand)
+    rsb_message *d_dec_in = nullptr;
+    rsb_decoded *d_decoded = nullptr;
+    size_t dec_in_cap = 0, decoded_cap = 0;
+    const rsb_message *last_list_dev = nullptr;  // collect_impl: where the batch's final list lies on the device (nullptr: only on the host)
+    uint64_t last_g0 = 0;                        // ... and the batch's stream position
     static constexpr uint32_t kNewAddersCap = 8192;
     std::vector<uint32_t> h_blk_counts, h_addrs;
     std::vector<uint2> h_new_adders;

@@ -195,6 +195,9 @@ struct MergeArgs {
     rsb_message *dst;
 };
 hipError_t launch_merge_modeac(const MergeArgs &m, hipStream_t s);
+// decode_fields.hip: n message records -> n rsb_decoded (struct modesMessage as decodeModesMessage / decodeModeAMessage leave it)
+hipError_t launch_decode_fields(const rsb_message *msgs_dev, uint32_t n, uint64_t batch_pos, uint32_t block_samples, rsb_decoded *out_dev,
+                                uint32_t *cpr_filtered_dev, hipStream_t s);
 hipError_t launch_wire_offsets(const WireArgs &w, void *temp, size_t temp_bytes, hipStream_t s);
 hipError_t launch_wire_write(const WireArgs &w, hipStream_t s);
 // first-add tables := "never" everywhere, 0 for address 0 and the n given addresses

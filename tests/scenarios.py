@@ -155,3 +155,117 @@ def bladerf_model(transfers, decimation=1):
         if length:
             bufs.append((start, length, stamp))
     return bufs
+
+
+# ---- frames for the field decode ------------------------------------------------------------------
+
+DECODE_POOL = [0x4840D6, 0xA1B2C3, 0x3C6DD0, 0x780123, 0x000001, 0xFFFFFE, 0x06A0F2, 0xE48A11]
+
+
+def crc24(frame, nbytes):
+    """Mode S parity (polynomial 0xFFF409) of the first nbytes - 3 bytes, bitwise (test helper; the library's is rsb_checksum)"""
+    rem = 0
+    for b in bytes(frame[:nbytes - 3]):
+        rem ^= b << 16
+        for _ in range(8):
+            rem = ((rem << 1) ^ 0xFFF409) & 0xFFFFFF if rem & 0x800000 else (rem << 1) & 0xFFFFFF
+    return rem
+
+
+def decode_frames(n, seed=21):
+    """n frames [n][14] that exercise every branch of decodeModesMessage's field decode (mode_s.c:557-716, 736-1474): every downlink
+    format the path accepts, DF17 / DF18 with every ME type (and every CF), Comm-D, single-bit damage on some DF11 / DF17 / DF18
+    frames, the 'cpr_filtered' position (mode_s.c:991-998), legal and illegal callsigns.  AP formats carry addresses of DECODE_POOL."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    frames = rng.integers(0, 256, (n, 14), dtype=np.uint8)
+    dfs = [17] * 10 + [18] * 6 + [11] * 2 + [0, 4, 5, 16, 20, 21, 24, 27, 31]
+    for i in range(n):
+        f = frames[i]
+        df = dfs[int(rng.integers(len(dfs)))]
+        f[0] = (df << 3) | (f[0] & 7) if df < 24 else (df << 3) | (f[0] & 7)
+        nbytes = 14 if df & 0x10 else 7
+        if df in (11, 17):  # these teach the reference's filter their address (mode_s.c:717-726), which holds about 2000: a small pool
+            a = DECODE_POOL[int(rng.integers(len(DECODE_POOL)))] ^ int(rng.integers(64))
+            f[1], f[2], f[3] = a >> 16, (a >> 8) & 255, a & 255
+        if df in (17, 18):
+            metype = int(rng.integers(32))
+            f[4] = (metype << 3) | (f[4] & 7)
+            kind = int(rng.integers(12))
+            if metype in (1, 2, 3, 4) and kind < 6:  # a callsign from the legal alphabet
+                chars = rng.choice(np.array([1, 2, 3, 26, 32, 48, 49, 57], dtype=np.int64), 8)
+                bits = 0
+                for c in chars:
+                    bits = (bits << 6) | int(c)
+                f[5:11] = np.frombuffer(bits.to_bytes(6, "big"), dtype=np.uint8)
+            if metype == 15 and kind < 4:  # altitude 0, longitude 0, latitude's low 12 bits 0
+                me = int.from_bytes(bytes(f[4:11]), "big")
+                me &= ~(((1 << 12) - 1) << 36)   # bits 9-20
+                me &= ~((1 << 17) - 1)          # bits 40-56
+                me &= ~(((1 << 12) - 1) << 17)  # low 12 bits of bits 23-39
+                f[4:11] = np.frombuffer(me.to_bytes(7, "big"), dtype=np.uint8)
+            if metype == 19 and kind < 2:
+                f[5] &= 0xFC  # east-west raw 0 in some velocity messages
+                f[6] = 0
+            if metype in (29, 31) and kind < 6:
+                pass  # random bits already reach every version / subtype
+        if df in (11, 17, 18):
+            crc = crc24(f, nbytes)
+            iid = 0
+            if df == 11 and rng.integers(3) == 0:  # DF11 with an interrogator id: needs a known address
+                a = DECODE_POOL[int(rng.integers(len(DECODE_POOL)))]
+                f[1], f[2], f[3] = a >> 16, (a >> 8) & 255, a & 255
+                crc = crc24(f, nbytes)
+                iid = int(rng.integers(1, 128))
+            crc ^= iid
+            f[nbytes - 3], f[nbytes - 2], f[nbytes - 1] = crc >> 16, (crc >> 8) & 255, crc & 255
+            if rng.integers(5) == 0 and not iid:  # one damaged bit outside the DF field and (so that the address stays known) the address
+                bit = int(rng.integers(32, nbytes * 8))
+                f[bit // 8] ^= 0x80 >> (bit % 8)
+        else:  # Address/Parity: parity XOR address of a known aircraft
+            a = DECODE_POOL[int(rng.integers(len(DECODE_POOL)))]
+            crc = crc24(f, nbytes) ^ a
+            f[nbytes - 3], f[nbytes - 2], f[nbytes - 1] = crc >> 16, (crc >> 8) & 255, crc & 255
+    return frames
+
+
+def records_from_structs(mm):
+    """rsb_message records (the decode kernel's input) from the reference's struct modesMessage images: exactly the members the
+    receive path itself produces (include/readsb_amd.h: rsb_message), the address and source as they are BEFORE the field decode."""
+    import numpy as np
+
+    import readsb_amd
+
+    d = mm.view(readsb_amd.DECODED_DTYPE).reshape(-1)
+    r = np.zeros(d.size, dtype=readsb_amd.MSG_DTYPE)
+    r["ts"] = d["timestampMsg"]
+    nbytes = d["msgbits"] // 8
+    r["msg"] = d["msg"]
+    for k in range(14):
+        r["msg"][:, k][nbytes <= k] = 0
+    r["msgbits"], r["msgtype"], r["crc"], r["correctedbits"], r["score"] = d["msgbits"], d["msgtype"], d["crc"], d["correctedbits"], d["score"]
+    df = d["msgtype"]
+    aa = (d["msg"][:, 1].astype(np.uint32) << 16) | (d["msg"][:, 2].astype(np.uint32) << 8) | d["msg"][:, 3]
+    es = (df == 17) | (df == 18)
+    modeac = df == 32
+    r["addr"] = np.where(es | (df == 11), aa, np.where(modeac, d["addr"], d["crc"]))
+    r["source"] = np.where(es, 7, np.where(df == 11, 4, np.where(modeac, 1, 3)))
+    r["iid"] = d["IID"]
+    r["signal"] = d["signalLevel"]
+    return r
+
+
+def mask_struct_images(mm):
+    """What a comparison of struct modesMessage images leaves out: msg[] past the frame (stale stack bytes in the reference, SURVEY.md
+    A.3) and sysTimestampMsg (wall clock)."""
+    import numpy as np
+
+    import readsb_amd
+
+    out = mm.copy().view(readsb_amd.DECODED_DTYPE).reshape(-1)
+    nbytes = out["msgbits"] // 8
+    for k in range(14):
+        out["msg"][:, k][nbytes <= k] = 0
+    out["sysTimestampMsg"] = 0
+    return out
