@@ -111,6 +111,14 @@ void rsbd_icaoFilterExpire(rsbd_modes *m); /* one flip; the reference's 60 s tim
 void rsbd_demodulate2400(rsbd_modes *m, struct rsbd_mag_buf *mag, rsbd_use_message_fn use, void *user);
 void rsbd_demodulate2400AC(rsbd_modes *m, struct rsbd_mag_buf *mag, rsbd_use_message_fn use, void *user);
 
+/* The same two calls with the field decode done on the device as well: `use` also receives the message's
+ * struct modesMessage image (rsb_decoded, include/readsb_amd.h) as decodeModesMessage (mode_s.c:557-716, 736-1474) /
+ * decodeModeAMessage (mode_ac.c:165-199) leave it, timestampMsg on the block's clock; what stays with the caller is listed at
+ * rsb_decoded (sysTimestampMsg, verbatim[], decodeCommB, the filter addition of mode_s.c:717-726 in ITS filter). */
+typedef void (*rsbd_use_decoded_fn)(void *user, const rsb_message *mm, const rsb_decoded *fields);
+void rsbd_demodulate2400_decoded(rsbd_modes *m, struct rsbd_mag_buf *mag, rsbd_use_decoded_fn use, void *user);
+void rsbd_demodulate2400AC_decoded(rsbd_modes *m, struct rsbd_mag_buf *mag, rsbd_use_decoded_fn use, void *user);
+
 /* ---- sdr_ifile.c: the "ifile" input driver -------------------------------------------------------- */
 
 /* What --device-type ifile --ifile <filename|-> --iformat <fmt> [--dcfilter] does on the reader thread

@@ -238,12 +238,13 @@ class RefHarness:
     @staticmethod
     def demod(iq: np.ndarray, fmt="UC8", nfix=1, modeac=False, dc_filter=False, verbatim=False, binary=None, full=False):
         """verbatim=True: also (msg, verbatim) of every message, with Modes.net_verbatim set (mode_s.c:427-430).
-        full=True: also every message's whole struct modesMessage (n x 416 bytes) as useModesMessage receives it, decodeCommB skipped.
+        full=True: also every message's whole struct modesMessage (n x 416 bytes) as useModesMessage receives it, decodeCommB skipped;
+        full="commb": the same with decodeCommB's work included.
         binary: REF_GPU_BIN = the same harness linked against integration/gpu_path.c + libreadsb_amd.so instead of demod_2400.o / convert.o"""
         with tempfile.TemporaryDirectory() as d:
             fin, fout = os.path.join(d, "in.iq"), os.path.join(d, "out.bin")
             iq_bytes(iq).tofile(fin)
-            subprocess.run([binary or REF_BIN, "demodfull" if full else "demodv" if verbatim else "demod", fmt, str(int(nfix)), str(int(modeac)), str(int(dc_filter)), fin, fout],
+            subprocess.run([binary or REF_BIN, "demodfullb" if full == "commb" else "demodfull" if full else "demodv" if verbatim else "demod", fmt, str(int(nfix)), str(int(modeac)), str(int(dc_filter)), fin, fout],
                            check=True, stderr=None if binary else subprocess.DEVNULL)
             raw = np.fromfile(fout, dtype=np.uint8)
         hdr = raw[:64].view("<u8")
@@ -275,6 +276,20 @@ class RefHarness:
         assert raw.size == n * (4 + MM_BYTES) + 4
         body = raw[:n * (4 + MM_BYTES)].reshape(n, 4 + MM_BYTES)
         return body[:, :4].copy().view("<i4").reshape(n), body[:, 4:].copy(), int(raw[-4:].view("<u4")[0])
+
+    @staticmethod
+    def timedecode(frames: np.ndarray, addrs=(), reps=1) -> dict:
+        """seconds of the reference's decodeModesMessage (decodeCommB included) over frames[n][14], reps passes, one thread"""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, 14)
+        addrs = np.ascontiguousarray(addrs, dtype="<u4")
+        with tempfile.TemporaryDirectory() as d:
+            fin = os.path.join(d, "in.bin")
+            with open(fin, "wb") as f:
+                f.write(np.array([addrs.size, frames.shape[0]], dtype="<u4").tobytes())
+                f.write(addrs.tobytes())
+                f.write(frames.tobytes())
+            out = subprocess.run([REF_BIN, "timedecode", fin, str(int(reps))], check=True, capture_output=True, text=True).stdout
+        return json.loads(out.strip().splitlines()[-1])
 
     @staticmethod
     def demodbufs(iq: np.ndarray, bufs, sub_len=0, fmt="UC8", nfix=1, modeac=False, dc_filter=False):

@@ -21,6 +21,9 @@
  *                                                                 useModesMessage receives it, WITHOUT decodeCommB's work (the harness is linked
  *                                                                 with -Wl,--wrap=decodeCommB and skips the call in this mode and in decodemsgs: comm_b.c
  *                                                                 is outside SURVEY.md section 8; every other mode calls the real one)
+ *   demodfullb (same arguments)                                    the whole struct as well, decodeCommB included: what an unmodified readsb hands on
+ *   timedecode <in.bin> <reps>                                     seconds the reference's decodeModesMessage (the real decodeCommB included) takes for the
+ *                                                                 frames of a decodemsgs input file, reps passes, one thread: the host-callback baseline
  *   decodemsgs <in.bin> <out.bin>                                  decodeModesMessage (mode_s.c:424-734) on frames from a file: in = {u32 naddr, u32 nframes,
  *                                                                 u32 addr[naddr] (icaoFilterAdd'ed first), u8 frame[nframes][14]}; out = per frame
  *                                                                 {i32 result, struct modesMessage}, then u32 stats_current.cpr_filtered
@@ -311,7 +314,8 @@ static int cmd_demod(int argc, char **argv) {
     uint8_t *iq = slurp(argv[6], &nbytes);
     init_modes(nfix, modeac, dc);
     capture_verbatim = Modes.net_verbatim = !strcmp(argv[1], "demodv");
-    capture_full = skip_commb = !strcmp(argv[1], "demodfull");
+    skip_commb = !strcmp(argv[1], "demodfull");
+    capture_full = skip_commb || !strcmp(argv[1], "demodfullb");
     run_stream(fmt, iq, nbytes, modeac);
     FILE *f = fopen(argv[7], "wb");
     if (!f) { perror(argv[7]); return 2; }
@@ -362,6 +366,42 @@ static int cmd_decodemsgs(int argc, char **argv) {
     uint32_t filtered = Modes.stats_current.cpr_filtered; /* mode_s.c:991-998 */
     fwrite(&filtered, 4, 1, f);
     fclose(f);
+    return 0;
+}
+
+static int cmd_timedecode(int argc, char **argv) {
+    if (argc != 4) return 2;
+    size_t nbytes;
+    uint8_t *in = slurp(argv[2], &nbytes);
+    int reps = atoi(argv[3]);
+    uint32_t naddr, nframes;
+    memcpy(&naddr, in, 4);
+    memcpy(&nframes, in + 4, 4);
+    if (nbytes != 8 + 4 * (size_t) naddr + 14 * (size_t) nframes) return 2;
+    init_modes(1, 0, 0);
+    for (uint32_t k = 0; k < naddr; ++k) {
+        uint32_t a;
+        memcpy(&a, in + 8 + 4 * (size_t) k, 4);
+        icaoFilterAdd(a);
+    }
+    const uint8_t *frames = in + 8 + 4 * (size_t) naddr;
+    struct timespec t0, t1;
+    uint64_t accepted = 0, sink = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int r = 0; r < reps; ++r)
+        for (uint32_t k = 0; k < nframes; ++k) {
+            struct modesMessage mm;
+            unsigned char frame[MODES_LONG_MSG_BYTES];
+            memset(&mm, 0, sizeof (mm));
+            memcpy(frame, frames + 14 * (size_t) k, 14);
+            if (decodeModesMessage(&mm, frame) == 0) {
+                ++accepted;
+                sink += mm.addr + mm.squawk + mm.cpr_lat; /* keep the work alive */
+            }
+        }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    double s = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    printf("{\"seconds\": %.6f, \"messages\": %" PRIu64 ", \"accepted\": %" PRIu64 ", \"sink\": %" PRIu64 "}\n", s, (uint64_t) nframes * reps, accepted, sink);
     return 0;
 }
 
@@ -501,8 +541,9 @@ static int cmd_crctab(int argc, char **argv) {
 int main(int argc, char **argv) {
     int rc = 2;
     if (argc >= 2) {
-        if (!strcmp(argv[1], "demod") || !strcmp(argv[1], "demodv") || !strcmp(argv[1], "demodfull")) rc = cmd_demod(argc, argv);
+        if (!strcmp(argv[1], "demod") || !strcmp(argv[1], "demodv") || !strcmp(argv[1], "demodfull") || !strcmp(argv[1], "demodfullb")) rc = cmd_demod(argc, argv);
         else if (!strcmp(argv[1], "decodemsgs")) rc = cmd_decodemsgs(argc, argv);
+        else if (!strcmp(argv[1], "timedecode")) rc = cmd_timedecode(argc, argv);
         else if (!strcmp(argv[1], "demodbufs")) rc = cmd_demodbufs(argc, argv);
         else if (!strcmp(argv[1], "time")) rc = cmd_time(argc, argv);
         else if (!strcmp(argv[1], "stats")) rc = cmd_stats(argc, argv);

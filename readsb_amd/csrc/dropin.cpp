@@ -203,6 +203,7 @@ struct rsbd_modes {
     uint16_t *d_mag = nullptr;
     unsigned max_length = 0;
     std::vector<rsb_message> out;
+    std::vector<rsb_decoded> fields;  // rsbd_demodulate2400*_decoded
 };
 
 extern "C" rsbd_modes *rsbd_modesInit(int nfix_crc, int device, unsigned max_length) {
@@ -244,7 +245,7 @@ extern "C" void rsbd_icaoFilterExpire(rsbd_modes *m) {
 
 namespace {
 
-void run_block(rsbd_modes *m, rsbd_mag_buf *mag, bool modes, bool modeac, rsbd_use_message_fn use, void *user) {
+void run_block(rsbd_modes *m, rsbd_mag_buf *mag, bool modes, bool modeac, rsbd_use_message_fn use, void *user, rsbd_use_decoded_fn use_decoded = nullptr) {
     if (!m || !mag || !mag->data) return;
     if (mag->length > m->max_length) {
         std::fprintf(stderr, "readsb_amd: mag_buf.length %u exceeds the %u given to rsbd_modesInit: block dropped\n", mag->length, m->max_length);
@@ -254,7 +255,11 @@ void run_block(rsbd_modes *m, rsbd_mag_buf *mag, bool modes, bool modeac, rsbd_u
     size_t n = 0;
     int rc = rsb_internal_submit_block(m->ctx, m->d_mag, mag->length, modes, modeac, mag->mean_level, mag->mean_power);
     if (rc == RSB_OK) {
-        rc = rsb_collect(m->ctx, m->out.data(), m->out.size(), &n);
+        if (use_decoded) {
+            m->fields.resize(m->out.size());
+            rc = rsb_collect_decoded(m->ctx, m->out.data(), m->fields.data(), m->out.size(), &n);
+        } else
+            rc = rsb_collect(m->ctx, m->out.data(), m->out.size(), &n);
         if (rc == RSB_EOVERFLOW && n > m->out.size()) {
             std::fprintf(stderr, "readsb_amd: %zu messages in one block exceed the %zu provided for; the rest is dropped\n", n, m->out.size());
             n = m->out.size();
@@ -268,7 +273,11 @@ void run_block(rsbd_modes *m, rsbd_mag_buf *mag, bool modes, bool modeac, rsbd_u
     for (size_t i = 0; i < n; ++i) {
         rsb_message &mm = m->out[i];
         mm.timestamp += mag->sampleTimestamp;  // demod_2400.c:320 / :649 are relative to the block's own clock
-        if (use) use(user, &mm);
+        if (use_decoded) {
+            m->fields[i].timestampMsg = mm.timestamp;
+            use_decoded(user, &mm, &m->fields[i]);
+        } else if (use)
+            use(user, &mm);
     }
 }
 
@@ -276,6 +285,8 @@ void run_block(rsbd_modes *m, rsbd_mag_buf *mag, bool modes, bool modeac, rsbd_u
 
 extern "C" void rsbd_demodulate2400(rsbd_modes *m, rsbd_mag_buf *mag, rsbd_use_message_fn use, void *user) { run_block(m, mag, true, false, use, user); }
 extern "C" void rsbd_demodulate2400AC(rsbd_modes *m, rsbd_mag_buf *mag, rsbd_use_message_fn use, void *user) { run_block(m, mag, false, true, use, user); }
+extern "C" void rsbd_demodulate2400_decoded(rsbd_modes *m, rsbd_mag_buf *mag, rsbd_use_decoded_fn use, void *user) { run_block(m, mag, true, false, nullptr, user, use); }
+extern "C" void rsbd_demodulate2400AC_decoded(rsbd_modes *m, rsbd_mag_buf *mag, rsbd_use_decoded_fn use, void *user) { run_block(m, mag, false, true, nullptr, user, use); }
 
 // ================================================================================== sdr_ifile.c
 

@@ -37,6 +37,8 @@ SYMBOLS = {
     "rsbd_icaoFilterExpire": (None, [_VP]),
     "rsbd_demodulate2400": (None, [_VP, C.POINTER(MagBuf), USE_FN, _VP]),
     "rsbd_demodulate2400AC": (None, [_VP, C.POINTER(MagBuf), USE_FN, _VP]),
+    "rsbd_demodulate2400_decoded": (None, [_VP, C.POINTER(MagBuf), _VP, _VP]),
+    "rsbd_demodulate2400AC_decoded": (None, [_VP, C.POINTER(MagBuf), _VP, _VP]),
     "rsbd_ifileOpen": (_VP, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
     "rsbd_ifileRun": (C.c_longlong, [_VP, USE_FN, _VP]),
     "rsbd_ifileFilterAdd": (None, [_VP, C.c_uint32]),

@@ -46,3 +46,30 @@ def test_reference_linked_against_the_library_reproduces_the_reference(name, bui
     assert (mv[:, 0] != mv[:, 1]).any(axis=1).sum() > 100  # repaired frames are in there
     for k in ("accepted0", "accepted1", "accepted2", "modeac"):
         assert st[k] == want_stats[k], k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mixed_fix1", "dense_fix2_ac"])
+def test_linked_reference_with_device_field_decode(name, built, monkeypatch):
+    """RSB_GPU_FIELDS=1: the shim no longer calls decodeModesMessage; the struct modesMessage it hands to useModesMessage is the
+    library's device-made image plus decodeCommB.  All 416 bytes of every message must be what the unmodified
+    reference hands on (tests/golden/fullb_*.npz), msg[] past the frame and the wall-clock member aside."""
+    from scenarios import mask_struct_images
+
+    assert os.access(REF_GPU_BIN, os.X_OK)
+    sc, kw = SCENARIOS[name]
+    z = np.load(os.path.join(GOLD, f"fullb_{name}.npz"))
+    want_stats = dict(zip(STAT_NAMES, (int(x) for x in z["stats"])))
+    monkeypatch.setenv("RSB_GPU_FIELDS", "1")
+    got, st, mm = RefHarness.demod(generate(sc), fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"], full="commb", binary=REF_GPU_BIN)
+    a, b = mask_struct_images(z["structs"]), mask_struct_images(mm)
+    assert a.size == b.size
+    for field in a.dtype.names:
+        bad = np.nonzero((a[field] != b[field]).reshape(a.size, -1).any(axis=1))[0] if a[field].dtype.kind != "f" else \
+            np.nonzero(a[field].view(f"u{a[field].dtype.itemsize}") != b[field].view(f"u{a[field].dtype.itemsize}"))[0]
+        assert not bad.size, f"{field}: {bad.size} messages differ, first {bad[0]}: want {a[field][bad[0]]!r} got {b[field][bad[0]]!r} (DF {a['msgtype'][bad[0]]})"
+    assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    for k in ("accepted0", "accepted1", "accepted2", "modeac"):
+        assert st[k] == want_stats[k], k
+    df = a["msgtype"]
+    assert ((df == 20) | (df == 21)).sum() > 10 and (df == 17).sum() > 100
