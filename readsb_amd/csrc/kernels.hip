@@ -31,6 +31,9 @@
 #ifndef RSB_SLICE_PREFETCH
 #define RSB_SLICE_PREFETCH 1
 #endif
+#ifndef RSB_RANK_CHEAP
+#define RSB_RANK_CHEAP 1
+#endif
 #ifdef RSB_STAGE_CLOCKS
 #define DBG_DECL uint32_t dbg_clk[5] = {0, 0, 0, 0, 0}, dbg_cnt[7] = {0, 0, 0, 0, 0, 0, 0}; uint64_t dbg_t = __builtin_readcyclecounter();
 #define DBG_STAGE(k) { const uint64_t t_ = __builtin_readcyclecounter(); dbg_clk[k] += (uint32_t)((t_ - dbg_t) >> 4); dbg_t = t_; }
@@ -1108,7 +1111,16 @@ __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t gro
         // The gated offsets in ascending order (the edge queue is filled bit by bit, not offset by offset): rank by counting, the
         // queue is short (about 25 entries).  From here on everything keeps that order -- (offset, phase) pairs, the frame list,
         // the ballot compactions -- so the wavefront's items leave sorted by (offset, phase).
-        if (ngq > 1 && !(a.debug_flags & 8)) {
+        if (RSB_RANK_CHEAP && ngq > 1 && ngq <= 64) {
+            // one register per lane, and the comparison as arithmetic on the cheap VALU operations (offsets are below 4096:
+            // (mine + 4095 - other) >> 12 is 1 exactly when other < mine) instead of v_cmp + v_addc through VCC
+            const uint32_t mine = lane < ngq ? W.gq[lane] : 0xfffu, mine_p = mine + 4095u;
+            uint32_t rank = 0;
+            for (uint32_t k = 0; k < ngq; ++k) rank += (mine_p - (uint32_t)W.gq[k]) >> 12;  // same address in every lane: a broadcast read
+            wave_sync();
+            if (lane < ngq) W.gq[rank] = (uint16_t)mine;  // offsets are distinct: so are the ranks
+            wave_sync();
+        } else if (ngq > 1 && !(a.debug_flags & 8)) {
             uint32_t mine[kGateCap / 64], rank[kGateCap / 64];
 #pragma unroll
             for (int h = 0; h < kGateCap / 64; ++h) {
