@@ -316,13 +316,18 @@ int rsb_stream_close(rsb_stream *st);   /* flush, then free the stream (not the 
 /* What decodeModesMessage (mode_s.c:557-716) and decodeExtendedSquitter (mode_s.c:736-1474) make of an accepted message, and
  * decodeModeAMessage (mode_ac.c:165-199) of a Mode A/C reply: every field of struct modesMessage (readsb.h:421-635) in the
  * reference's own x86-64 layout, 416 bytes, so that a caller copies the record over its struct modesMessage and hands it to
- * useModesMessage (integration/gpu_path.c does; its _Static_asserts hold the offsets against the reference's header).  Bit
- * fields are given as the 32-bit words they occupy (gcc allocates them from bit 0 up, in declaration order).
+ * useModesMessage (integration/gpu_path.c does with RSB_GPU_FIELDS=1; its _Static_asserts hold every member's offset against the
+ * reference's header).  Bit-fields are given as the bytes / 32-bit words they occupy (gcc allocates them from bit 0 up, in
+ * declaration order).
  * Left for the caller: sysTimestampMsg (wall clock, demod_2400.c:323), verbatim[] (only kept with Modes.net_verbatim,
  * mode_s.c:427-430), decodeCommB for DF20/21 (comm_b.c: the BDS heuristics, out of scope -- MB[] is filled), and the tracker's
  * fields (reduce_forward, cpr_decoded ...).  msg[] holds the first msgbits / 8 bytes, the rest is zero (the reference leaves stale
- * stack bytes there).  The records are read and written as 32-bit words: msgs_dev and out_dev must be 4-byte aligned.  Mode A/C: the reference zeroes its struct once per block, not per message (demod_2400.c:482), so an altitude
- * decoded for one reply stays in the struct for the later replies of the same block that decode none: reproduced. */
+ * stack bytes there).  The records are read and written as 32-bit words: msgs_dev and out_dev must be 4-byte aligned.
+ * Mode A/C: the reference zeroes its struct once per block, not per message (demod_2400.c:482), so an altitude decoded for one
+ * reply stays in the struct for the later replies of the same block that decode none: reproduced.
+ * Why on the device: the reference's decodeModesMessage handles 28 M messages per second and core (oracle/_ref/ref_harness
+ * timedecode on the GPU box's host), a benchmark step delivers 0.73 M messages in 2.1 ms = 350 M per second; the kernel decodes
+ * 6.2 G messages per second (profiles/r3_decode_rate.json). */
 typedef struct rsb_decoded {
     uint64_t timestampMsg;             /*   0 */
     uint64_t sysTimestampMsg;          /*   8  0: the caller's */
