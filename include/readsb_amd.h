@@ -224,7 +224,9 @@ int rsb_collect(rsb_ctx *ctx, rsb_message *out, size_t cap, size_t *n_out);
  * rsb_collect_prepare enqueues that chain for the oldest submitted batch on the context's own stream and returns without waiting;
  * called for every channel before the first rsb_collect, the chains of all channels run side by side and the collects find their
  * results ready.  Optional (rsb_collect does it otherwise) and a no-op for batches that need the host's step-by-step path.
- * Filter changes made between prepare and collect (rsb_filter_add*, rsb_filter_expire) apply from the next batch on. */
+ * A filter or superset change made from outside (rsb_filter_add*, rsb_filter_expire, rsb_superset_add) while a chain is enqueued -- by
+ * this call, or by the library itself for a batch submitted ahead -- discards that chain: the batch is pruned and replayed again when
+ * it is collected, against the filter as it is then (what the reference's loop sees between two demodulate2400 calls). */
 int rsb_collect_prepare(rsb_ctx *ctx);
 /* N blocks x C channels in one call (last row): channel i's batch iq_dev[i][0 .. nsamples[i]) is submitted on
  * `stream` for every i, and rsb_collect_many fetches every channel's messages into out[i][0 .. cap[i]) (n_out[i] of them).

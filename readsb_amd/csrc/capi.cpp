@@ -435,6 +435,23 @@ void collect_ahead(rsb_ctx *c) {
     if (replay_enqueue(c, nb, kept_items_bound(c, nb), true, s) != RSB_OK) nb.chain_enqueued = false;  // collect will try again and report
 }
 
+// A change of the filter or of the prune's superset from outside while the next batch's chain is already on the replay stream
+// (collect_ahead / rsb_collect_prepare put it there): that chain ran against the old state.  Drop it -- the collect then prunes and
+// replays the batch again, against the state as it is when the batch is collected, which is what a caller that changes the
+// filter between two collects means.
+int drop_enqueued_chain(rsb_ctx *c) {
+    if (!c->any_pending()) return RSB_OK;
+    rsb_slot &nb = c->collect_slot();
+    if (!nb.pending || !nb.chain_enqueued) return RSB_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->replay_stream));
+    nb.chain_enqueued = false;
+    nb.pruned = false;  // the superset may have grown: the prune runs again at collect time (it rebuilds everything it writes)
+    c->filter_dirty = true;
+    c->tables_valid = false;  // the dropped round's seed entries are in the tables
+    return RSB_OK;
+}
+
 const CrcTables &tables_for(int fix_bits) {
     static const CrcTables t0(0), t1(1), t2(2);
     return fix_bits <= 0 ? t0 : (fix_bits == 1 ? t1 : t2);
@@ -546,6 +563,10 @@ int rsb_filter_add_many(rsb_ctx *c, const uint32_t *addrs, size_t n) {
     if (!c || (!addrs && n)) return RSB_EINVAL;
     if (n == 0) return RSB_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    {
+        const int rc = drop_enqueued_chain(c);
+        if (rc != RSB_OK) return rc;
+    }
     // the scans of pending batches set bits of the superset with atomics: wait for them before the host touches its words
     for (rsb_slot &b : c->slots)
         if (b.pending) HIP_TRY(c, hipEventSynchronize(b.ev[3]));
@@ -575,6 +596,10 @@ int rsb_filter_add_many(rsb_ctx *c, const uint32_t *addrs, size_t n) {
 int rsb_filter_expire(rsb_ctx *c) {
     if (!c) return RSB_EINVAL;
     // the device bitmap stays a superset (it only ever grows), which is all the prune needs
+    {
+        const int rc = drop_enqueued_chain(c);
+        if (rc != RSB_OK) return rc;
+    }
     c->replay.filter().expire();
     c->filter_dirty = true;
     return RSB_OK;
@@ -638,7 +663,9 @@ int rsb_superset_add(rsb_ctx *c, const uint32_t *addrs, size_t n) {
     if (!c || (!addrs && n)) return RSB_EINVAL;
     if (n == 0) return RSB_OK;
     std::vector<uint32_t> words;
-    const int rc = fetch_bitmap(c, words);
+    int rc = drop_enqueued_chain(c);
+    if (rc != RSB_OK) return rc;
+    rc = fetch_bitmap(c, words);
     if (rc != RSB_OK) return rc;
     for (size_t i = 0; i < n; ++i) words[(addrs[i] & 0xffffffu) >> 5] |= 1u << (addrs[i] & 31);
     HIP_TRY(c, hipMemcpy(c->d_bitmap, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -669,7 +696,7 @@ static int enqueue_before_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, hipS
     return RSB_OK;
 }
 
-static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s);
+static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s, bool record_scan_end = true);
 
 static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
     int rc = enqueue_before_scan(c, b, a, s);
@@ -678,8 +705,8 @@ static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t n
     return enqueue_after_scan(c, b, a, nsamples, s);
 }
 
-static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
-    HIP_TRY(c, hipEventRecord(b.ev[1], s));
+static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s, bool record_scan_end) {
+    if (record_scan_end) HIP_TRY(c, hipEventRecord(b.ev[1], s));
     // The prune runs at the head of the batch's replay chain, on the context's own stream (rsb_collect, or collect_ahead while
     // the batch before is being delivered), not here: the caller's stream then carries the scans of successive batches back to
     // back, and the prune sees whatever the caller has added to the superset in between (RSB_FLAG_DEFER_PRUNE relies on that).
@@ -1321,13 +1348,15 @@ int rsb_submit_many(rsb_ctx *const *ctx, size_t nch, const void *const *iq_dev, 
             c0->d_many_args = nullptr;
             c0->h_many_args = nullptr;
             c0->many_args_cap = 0;
-            HIP_TRY(c0, hipMalloc((void **)&c0->d_many_args, nch * sizeof(BatchArgs)));
+            HIP_TRY(c0, hipMalloc((void **)&c0->d_many_args, 2 * nch * sizeof(BatchArgs)));  // two halves, as the pinned staging
             HIP_TRY(c0, hipHostMalloc((void **)&c0->h_many_args, 2 * nch * sizeof(BatchArgs), hipHostMallocDefault));
             c0->many_args_cap = nch;
             for (hipEvent_t &ev : c0->many_args_read)
                 if (!ev) HIP_TRY(c0, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         }
-        // the staging half used two calls ago: its upload has long run, but the host may be that far ahead of the stream
+        // the halves (pinned staging and device copy) used two calls ago: their scan has long run, but the host may be that far ahead
+        // of the stream -- or the calls may go to different streams, where the device copy of one call must not be overwritten while
+        // the scan of the other still loads its arguments: the event is recorded behind the scan launch
         const unsigned half = c0->many_calls++ & 1u;
         if (c0->many_args_pending[half]) HIP_TRY(c0, hipEventSynchronize(c0->many_args_read[half]));
         BatchArgs *h = c0->h_many_args + half * c0->many_args_cap;
@@ -1338,9 +1367,8 @@ int rsb_submit_many(rsb_ctx *const *ctx, size_t nch, const void *const *iq_dev, 
             const int rc = enqueue_before_scan(c, c->submit_slot(), h[i], s, false);
             if (rc != RSB_OK) return rc;
         }
-        HIP_TRY(c0, hipMemcpyAsync(c0->d_many_args, h, nch * sizeof(BatchArgs), hipMemcpyHostToDevice, s));
-        HIP_TRY(c0, hipEventRecord(c0->many_args_read[half], s));
-        c0->many_args_pending[half] = true;
+        BatchArgs *d_args = c0->d_many_args + half * c0->many_args_cap;
+        HIP_TRY(c0, hipMemcpyAsync(d_args, h, nch * sizeof(BatchArgs), hipMemcpyHostToDevice, s));
         uint64_t total = 0;
         for (size_t i = 0; i < nch; ++i) total += nsamples[i];
         for (size_t i = 0; i < nch; ++i) {  // the one launch's time is shared out by samples (rsb_timing.scan_ms)
@@ -1348,10 +1376,13 @@ int rsb_submit_many(rsb_ctx *const *ctx, size_t nch, const void *const *iq_dev, 
             b.scan_share = total ? (float)((double)nsamples[i] / (double)total) : 0.0f;
             HIP_TRY(ctx[i], hipEventRecord(b.ev[0], s));
         }
-        HIP_TRY(c0, launch_scan_many(c0->cfg.input_format, c0->d_many_args, (uint32_t)nch, groups, s));
+        HIP_TRY(c0, launch_scan_many(c0->cfg.input_format, d_args, (uint32_t)nch, groups, s));
+        HIP_TRY(c0, hipEventRecord(c0->many_args_read[half], s));
+        c0->many_args_pending[half] = true;
+        for (size_t i = 0; i < nch; ++i) HIP_TRY(ctx[i], hipEventRecord(ctx[i]->submit_slot().ev[1], s));  // the scan's end, before any channel's Mode A/C kernels
         for (size_t i = 0; i < nch; ++i) {
             rsb_ctx *c = ctx[i];
-            const int rc = enqueue_after_scan(c, c->submit_slot(), h[i], nsamples[i], s);
+            const int rc = enqueue_after_scan(c, c->submit_slot(), h[i], nsamples[i], s, false);
             if (rc != RSB_OK) return rc;
         }
         return RSB_OK;

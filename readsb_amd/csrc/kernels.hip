@@ -1,15 +1,18 @@
 // kernels.hip -- gfx950 kernels of the receive path.
 //
-//   k_scan      persistent workgroups, every wavefront on strips of 2768 scan offsets: convert.c (IQ -> magnitude
-//               through a folded 32 KB LUT in LDS, magnitudes live in LDS only) -> demod_2400.c:109-155 as bit-sliced
-//               edge patterns (4 offsets x 6 passes per lane and instruction) -> :158-172 on the ~5 % that
-//               survive -> :179-286 five trial phases, first the DF field, then dense 56-/112-bit slicing, one lane per
-//               frame -> crc.c:67-82 / :383-406 -> the filter-independent half of mode_s.c:311-409.  Emits one 8-byte
-//               item per trial phase that can still score >= 0 under some filter state, and marks every address the
-//               filter could ever learn (mode_s.c:717-726) in a 2^24-bit set.
-//   k_prune     drops items that need a filter member which is not in that superset (safe: such a
-//               phase scores < 0 whatever happened before it; demod_2400.c:290,304-310).
-//   sort        hipCUB radix sort of the kept items by (offset, phase).
+//   k_scan      persistent grid, one 1024-thread workgroup per CU; its 16 wavefronts work alone (no workgroup barrier after the
+//               table set-up) on strips of 2768 scan offsets, handed out in chunks of consecutive strips from a two-level
+//               counter: convert.c (IQ -> magnitude; UC8 through a 'radial' table in LDS indexed by one v_dot4, magnitudes
+//               live in LDS only) -> demod_2400.c:109-155 as bit-sliced edge patterns (4 offsets x 6 passes per lane and
+//               instruction) -> :158-172 on the ~3 % that survive -> :179-286 five trial phases, first the DF field, then
+//               dense 56-/112-bit slicing, one lane per frame (v_dot2 on biased sample pairs) -> crc.c:67-82 / :383-406 by
+//               linearity -> the filter-independent half of mode_s.c:311-409.  Emits one 8-byte item per trial phase that can
+//               still score >= 0 under some filter state, sorted by (offset, phase) within a chunk, and marks every address the
+//               filter could ever learn (mode_s.c:717-726) in a 2^24-bit set.  k_scan_many: the channels of rsb_submit_many.
+//   k_prune_*   the ordered prune: drops items that need a filter member which is not in that superset (safe: such a phase
+//               scores < 0 whatever happened before it; demod_2400.c:290,304-310) and packs the chunks' runs in stream order
+//               (summary of the adder bitmap in LDS -> keep masks -> chunk counts -> offsets -> write): no sort.
+//   k_prune + rocPRIM radix sort   the fallback for a batch in which a scan wavefront overflowed an LDS queue.
 //   k_replay_*  the sequential rules on the device (demod_2400.c:289-374): per-block greedy walk, the ICAO filter as a
 //               fixed point over a "first added at" table, k_replay_emit writes the rsb_message records.
 //   k_finalize  (host-replay path) re-slices the kept offsets into full records (5 x 14 message bytes + the signal
@@ -58,7 +61,7 @@
 #define RSB_PREFETCH_EARLY 1
 #endif
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <cmath>
 #include <type_traits>
@@ -401,25 +404,23 @@ __device__ void slow_item(const BatchArgs &a, const uint16_t *d, uint32_t g, int
 // ------------------------------------------------------------------------------------------------
 // the scan kernel: wave-autonomous strips
 //
-// One 768-thread workgroup per CU shares the 32 KB folded UC8 table and the small CRC tables; after
-// that each of its 12 wavefronts works alone on strips of 3792 scan offsets with its own 9.75 KB of
-// LDS (4096 magnitudes = the strip + a 304-sample halo, and three small queues).  A strip goes
-// through all stages inside its wavefront, so no workgroup barrier is ever executed: while one
-// wavefront is in a stage that keeps few lanes busy, the other wavefronts of the SIMD are in others.
+// One 1024-thread workgroup per CU shares the UC8 radial table (32.3 KB), the CRC group-syndrome rows, the repair tables of
+// --fix and the Bloom filter over them; after that set-up each of its 16 wavefronts works alone on strips of 2768 scan offsets
+// (kScanStrip) with its own 7 KB of LDS (WaveShared: 3072 magnitudes = the strip + a 304-sample halo, and three small queues).
+// A strip goes through all stages inside its wavefront, so no workgroup barrier is ever executed: while one wavefront is in a
+// stage that keeps few lanes busy, the other three wavefronts of its SIMD are in others.  Strips are handed out in chunks
+// (scan_body: grab_chunk), whichever wavefront is free next takes the next chunk.
 //
-//   1. convert: 8 passes, lane l of pass t owns the 8 samples of chunk 64t + l (one 16-byte load of
-//      raw IQ per pass, fetched one strip ahead into registers).  While the chunk is still in registers
-//      the comparisons m[s] < m[s+1] and m[s] > m[s+1] are taken with packed saturating subtracts and
-//      their sign bits shifted into bit-sliced words: byte k of a lane's word, bit t = sample k of
-//      chunk 64t + l.
-//   2. the edge patterns of demod_2400.c:109-155 on those words: "sample s + j" is byte (k + j) % 8
-//      of this lane, the next lane or the one after, so a shift is a v_alignbyte and every logic
-//      instruction decides 4 offsets x 8 passes per lane, 2048 offsets per wavefront.
-//   3. the ~5 % of offsets that survive are compacted into an LDS queue and take the arithmetic gate
-//      (:158-172), one lane per offset.
-//   4. (gated offset, trial phase) pairs, one lane each: the first five bits (the DF) decide the
-//      length class (:272-285).
-//   5. one lane per frame: all 56 / 112 bits, CRC syndrome by linearity, classification -> item.
+//   1. convert: kScanPasses passes, lane l of pass t owns the 8 samples of chunk 64t + l (one 16-byte load of raw IQ per pass,
+//      fetched one strip ahead into registers).  While the chunk is still in registers the comparisons m[s] < m[s+1] and
+//      m[s] > m[s+1] are taken with packed saturating subtracts and their sign bits shifted into bit-sliced words: byte k of a
+//      lane's word, bit t = sample k of chunk 64t + l.
+//   2. the edge patterns of demod_2400.c:109-155 on those words: "sample s + j" is byte (k + j) % 8 of this lane, the next lane
+//      or the one after, so a shift is a v_alignbyte and every logic instruction decides 4 offsets x kScanPasses passes per lane.
+//   3. the ~3 % of offsets that survive are compacted into an LDS queue and take the arithmetic gate (:158-172), one lane per
+//      offset; the gated offsets (~0.9 %) are ranked into ascending order.
+//   4. (gated offset, trial phase) pairs, one lane each: the first five bits (the DF) decide the length class (:272-285).
+//   5. one lane per frame: all 56 / 112 bits in groups of five, CRC syndrome by linearity, classification -> item.
 //
 // Slicing: bit k = 5u + v of trial phase tp is the sign of correlator (tp + 12v) % 5 at sample
 // e0 + 12u + (tp + 12v) / 5.  Whatever tp (4..8) and the parity of e0, the taps of bit v of a group
@@ -3139,26 +3140,26 @@ hipError_t launch_prune_ordered(const BatchArgs &a, hipStream_t s) {
 }
 
 size_t sort_temp_bytes(uint32_t max_items) {
-    size_t sort_bytes = 0, uniq_bytes = 0, flag_bytes = 0;
-    hipcub::DoubleBuffer<uint64_t> k(nullptr, nullptr);
-    hipcub::DoubleBuffer<uint32_t> v(nullptr, nullptr);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k, v, (int)max_items, 0, 35);
-    (void)hipcub::DeviceSelect::Unique(nullptr, uniq_bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)max_items);
-    (void)hipcub::DeviceSelect::Flagged(nullptr, flag_bytes, hipcub::CountingInputIterator<uint32_t>(0), (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                        (uint32_t *)nullptr, (int)max_items);
+    // work memory of the fallback sort (rocPRIM radix sort of 35-bit keys), the unique step behind it, and the wire encoder's prefix sum
+    size_t sort_bytes = 0, uniq_bytes = 0, scan_bytes = 0;
+    rocprim::double_buffer<uint64_t> k(nullptr, nullptr);
+    rocprim::double_buffer<uint32_t> v(nullptr, nullptr);
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, k, v, (size_t)max_items, 0u, 35u);
+    (void)rocprim::unique(nullptr, uniq_bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)max_items);
+    (void)rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)max_items + 1, rocprim::plus<uint32_t>());
     size_t m = sort_bytes > uniq_bytes ? sort_bytes : uniq_bytes;
-    if (flag_bytes > m) m = flag_bytes;
+    if (scan_bytes > m) m = scan_bytes;
     return m + 256;
 }
 
 hipError_t launch_sort(const BatchArgs &a, uint32_t n_items, void *temp, size_t temp_bytes, int *sorted_buf, hipStream_t s) {
     *sorted_buf = 0;
     if (n_items == 0) return hipSuccess;
-    hipcub::DoubleBuffer<uint64_t> k(a.skeys[0], a.skeys[1]);
-    hipcub::DoubleBuffer<uint32_t> v(a.sinfo[0], a.sinfo[1]);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k, v, (int)n_items, 0, 35, s);
+    rocprim::double_buffer<uint64_t> k(a.skeys[0], a.skeys[1]);
+    rocprim::double_buffer<uint32_t> v(a.sinfo[0], a.sinfo[1]);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, k, v, (size_t)n_items, 0u, 35u, s);
     if (e != hipSuccess) return e;
-    *sorted_buf = (k.Current() == a.skeys[1]) ? 1 : 0;
+    *sorted_buf = (k.current() == a.skeys[1]) ? 1 : 0;
     return hipSuccess;
 }
 
@@ -3169,7 +3170,7 @@ hipError_t launch_unique_finalize(const BatchArgs &a, uint32_t n_items, int sort
     hipLaunchKernelGGL(k_keys_to_g, dim3(512), dim3(kThreads), 0, s, a.skeys[sorted_buf], gtmp, n_items);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = hipcub::DeviceSelect::Unique(temp, temp_bytes, gtmp, a.surv_g, &a.counters[kCntSurvivors], (int)n_items, s);
+    e = rocprim::unique(temp, temp_bytes, gtmp, a.surv_g, &a.counters[kCntSurvivors], (size_t)n_items, rocprim::equal_to<uint32_t>(), s);
     if (e != hipSuccess) return e;
     return by_format(a.fmt, [&](auto F) {
         hipLaunchKernelGGL(k_finalize<decltype(F)::value>, dim3(8192), dim3(64), 0, s, a);
@@ -3305,13 +3306,13 @@ __global__ void k_wire_write(const WireArgs w) {
 
 hipError_t launch_wire_offsets(const WireArgs &w, void *temp, size_t temp_bytes, hipStream_t s) {
     size_t need = 0;
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, w.off, w.off, (int)(w.n + 1), s);
+    hipError_t e = rocprim::exclusive_scan(nullptr, need, w.off, w.off, 0u, (size_t)w.n + 1, rocprim::plus<uint32_t>(), s);
     if (e != hipSuccess) return e;
     if (need > temp_bytes) return hipErrorOutOfMemory;
     hipLaunchKernelGGL(k_wire_sizes, dim3((w.n + kThreads) / kThreads), dim3(kThreads), 0, s, w);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return hipcub::DeviceScan::ExclusiveSum(temp, need, w.off, w.off, (int)(w.n + 1), s);
+    return rocprim::exclusive_scan(temp, need, w.off, w.off, 0u, (size_t)w.n + 1, rocprim::plus<uint32_t>(), s);
 }
 
 hipError_t launch_wire_write(const WireArgs &w, hipStream_t s) {

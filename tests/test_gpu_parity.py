@@ -263,6 +263,46 @@ def test_filter_expiry_between_batches(built):
     assert whole.size >= outs[0].size
 
 
+def test_filter_change_reaches_a_batch_submitted_ahead(built):
+    """Two batches submitted, the first collected (the library then puts the second one's replay chain on its stream by itself), THEN the
+    filter is changed from outside: the change must reach the second batch, as it does when the batches go one at a time."""
+    import torch
+
+    sc, kw = SCENARIOS["mixed_fix1"]
+    iq = generate(sc).reshape(-1, 2)
+    cut = 8 * 131072
+    cold, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"]).run_stream(iq)
+    known = sorted(set(int(a) & 0xFFFFFF for a in cold["addr"]))[:64] + _addresses(40, 5)  # addresses whose Address/Parity replies then decode
+
+    def change(ch, what):
+        if what == "expire":
+            ch.filter_expire()
+            ch.filter_expire()
+        else:
+            ch.filter_add_many(known)
+
+    d = torch.from_numpy(np.ascontiguousarray(iq)).to(torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    for what in ("expire", "add"):
+        ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=1 << 23)
+        want = [ch.process_host(iq[:cut])]
+        change(ch, what)
+        want.append(ch.process_host(iq[cut:]))
+        ch.close()
+        ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=1 << 23)
+        ch.submit(d.data_ptr(), cut)
+        ch.submit(d.data_ptr() + cut * 2, iq.shape[0] - cut)
+        first = ch.collect(1 << 15).copy()
+        change(ch, what)
+        second = ch.collect(1 << 15).copy()
+        assert ch.timing()["replay_on_device"] == 1
+        ch.close()
+        assert first.tobytes() == want[0].tobytes(), what
+        assert second.size == want[1].size and second.tobytes() == want[1].tobytes(), what
+    # and the add matters: more messages than the cold run has in its second part
+    assert want[0].size + want[1].size > len(cold)
+
+
 def test_external_add_between_batches(built):
     """An icaoFilterAdd from outside between batches rebuilds the device tables from the host filter:
     everything the device replay learned before must have reached the host filter."""
