@@ -204,3 +204,140 @@ def simulate_sharded(chs, total_samples: int, segment_samples: int, get_segment,
             msgs, flt = shard_finish(chs[k % n], union, flt if k >= 1 else None, cap)
             out.append(msgs)
     return np.concatenate(out) if out else np.zeros(0, dtype=MSG_DTYPE)
+
+
+# ---- one recording in shards WITHOUT the serial ring: the filter coupling as a fixed point over the shards ----------------------
+#
+# The only thing a shard needs from the shards before it is the SET of addresses they taught the filter (mode_s.c:717-726).  Every
+# rank therefore replays its shard at once, in parallel with all others, under an assumption about that set -- the exact filter at
+# the start of the round plus every address the earlier shards of the round COULD add (their scans' adder lists: a clean DF17 or
+# DF11 nearly always is accepted) -- and the assumption is checked afterwards: the ranks all-gather what their shards really added,
+# and a rank whose true starting filter differs from the assumed one decodes its shard again with the true one.  By induction over
+# the shards (shard 0's starting filter is always exact) the loop ends after at most `world` passes with exactly the serial result;
+# with the optimistic start it normally ends after the first.  Prune, replay, emit and the record copy all run in parallel; what is
+# serial is two small all-gathers per round.
+
+def _gather_lists_u32(mine: np.ndarray, device: torch.device) -> list[np.ndarray]:
+    """variable-length all-gather of uint32 lists -> one list per rank (on every rank)"""
+    _, n = world()
+    mine = np.ascontiguousarray(mine, dtype=np.uint32)
+    if n == 1:
+        return [mine]
+    counts = gather_counts(int(mine.size), device)
+    longest = max(1, max(counts))
+    buf = torch.zeros(longest, dtype=torch.int64, device=device)
+    if mine.size:
+        buf[:mine.size] = torch.from_numpy(mine.astype(np.int64)).to(device)
+    out = [torch.zeros_like(buf) for _ in range(n)]
+    dist.all_gather(out, buf)
+    return [o.cpu().numpy()[:c].astype(np.uint32) for o, c in zip(out, counts)]
+
+
+class _Shard:
+    """one rank's side of the fixed point (also driven directly by simulate_parallel)"""
+
+    def __init__(self, ch, cap):
+        self.ch, self.cap = ch, cap
+        self.seen = np.zeros(0, dtype=np.uint32)  # the adder list of this rank's context so far (it only grows)
+        self.redone = 0
+
+    def scan(self, start, nsamples, dev_ptr, carry):
+        self.args = (start, nsamples, dev_ptr, carry)
+        now = shard_scan(self.ch, start, nsamples, dev_ptr, carry)
+        new = np.setdiff1d(now, self.seen)
+        self.seen = now
+        return new
+
+    def replay(self, assumed: np.ndarray, superset: np.ndarray):
+        """collect under the assumption that the filter holds exactly `assumed` -> (messages, addresses this shard added)"""
+        self.ch.superset_add(superset)
+        have = self.ch.filter_export()
+        self.ch.filter_add_many(np.setdiff1d(assumed, have))
+        msgs = self.ch.collect(self.cap).copy()
+        return msgs, np.setdiff1d(self.ch.filter_export(), assumed)
+
+    def redo(self, true_filter: np.ndarray, superset: np.ndarray):
+        """the assumption was wrong: the shard again from a context that holds the true filter (rsb_reset forgets the optimistic one)"""
+        self.redone += 1
+        self.ch.reset()
+        self.ch.filter_add_many(true_filter)
+        self.seen = shard_scan(self.ch, *self.args)
+        return self.replay(true_filter, superset)
+
+
+def decode_recording_parallel(ch, total_samples: int, segment_samples: int, get_segment, get_carry, device: torch.device, cap: int = 1 << 20,
+                              optimistic: bool = True, stats: dict | None = None):
+    """decode_recording_sharded's result without its serial ring (see above).  ch: this rank's Channel, created with defer_prune=True.
+    optimistic=False starts from "the earlier shards of the round add nothing" (tests: forces the correction passes).
+    -> list of (segment index, messages) of this rank's segments."""
+    from . import BLOCK
+
+    assert segment_samples % BLOCK == 0 and segment_samples > 0
+    rank, n = world()
+    nseg = (total_samples + segment_samples - 1) // segment_samples
+    me = _Shard(ch, cap)
+    f_in = np.zeros(0, dtype=np.uint32)  # the exact filter at the start of the round, the same on every rank
+    mine, passes = [], 0
+    for j in range((nseg + n - 1) // n):
+        k = j * n + rank
+        active = k < nseg
+        new = np.zeros(0, dtype=np.uint32)
+        if active:
+            start, stop = k * segment_samples, min(total_samples, (k + 1) * segment_samples)
+            new = me.scan(start, stop - start, get_segment(start, stop), get_carry(start))
+        potential = _gather_lists_u32(new, device)
+        superset = np.unique(np.concatenate(potential)) if potential else new
+        assumed = np.unique(np.concatenate([f_in] + (potential[:rank] if optimistic else [])))
+        msgs, added = me.replay(assumed, superset) if active else (None, np.zeros(0, dtype=np.uint32))
+        while True:
+            passes += 1
+            adds = _gather_lists_u32(added, device)
+            true_in = np.unique(np.concatenate([f_in] + adds[:rank]))
+            wrong = active and not np.array_equal(true_in, assumed)
+            if wrong:
+                assumed = true_in
+                msgs, added = me.redo(true_in, superset)
+            if max_over_ranks(1.0 if wrong else 0.0, device) == 0.0:
+                break
+        f_in = np.unique(np.concatenate([f_in] + adds))
+        if active:
+            mine.append((k, msgs))
+    if stats is not None:
+        stats.update(redone=me.redone, passes=passes, rounds=(nseg + n - 1) // n)
+    return mine
+
+
+def simulate_parallel(chs, total_samples: int, segment_samples: int, get_segment, get_carry, cap: int = 1 << 20, optimistic: bool = True,
+                      stats: dict | None = None) -> np.ndarray:
+    """decode_recording_parallel's schedule with len(chs) channels in one process and no torch.distributed: 'rank' r is chs[r]."""
+    n = len(chs)
+    nseg = (total_samples + segment_samples - 1) // segment_samples
+    shards = [_Shard(ch, cap) for ch in chs]
+    f_in = np.zeros(0, dtype=np.uint32)
+    out, passes = [], 0
+    for j in range((nseg + n - 1) // n):
+        ks = [k for k in range(j * n, (j + 1) * n) if k < nseg]
+        potential = []
+        for k in ks:
+            start, stop = k * segment_samples, min(total_samples, (k + 1) * segment_samples)
+            potential.append(shards[k % n].scan(start, stop - start, get_segment(start, stop), get_carry(start)))
+        superset = np.unique(np.concatenate(potential))
+        assumed = [np.unique(np.concatenate([f_in] + (potential[:r] if optimistic else []))) for r in range(len(ks))]
+        results = [shards[r].replay(assumed[r], superset) for r in range(len(ks))]
+        while True:
+            passes += 1
+            adds = [a for _, a in results]
+            any_wrong = False
+            for r in range(len(ks)):  # (every 'rank' decides from the same gathered lists, as the ranks of a job do)
+                true_in = np.unique(np.concatenate([f_in] + adds[:r]))
+                if not np.array_equal(true_in, assumed[r]):
+                    assumed[r] = true_in
+                    results[r] = shards[r].redo(true_in, superset)
+                    any_wrong = True
+            if not any_wrong:
+                break
+        f_in = np.unique(np.concatenate([f_in] + [a for _, a in results]))
+        out.extend(m for m, _ in results)
+    if stats is not None:
+        stats.update(redone=sum(s.redone for s in shards), passes=passes, rounds=(nseg + n - 1) // n)
+    return np.concatenate(out) if out else np.zeros(0, dtype=MSG_DTYPE)

@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -111,6 +112,19 @@ class _FakeChannel:
     def filter_export(self):
         return np.array(sorted(self.filter), dtype=np.uint32)
 
+    def reset(self):
+        self.filter, self.superset, self.pending = set(), set(), None
+        self.resets = getattr(self, "resets", 0) + 1
+
+
+class _BoastingChannel(_FakeChannel):
+    """its scans announce an address (5000 + segment) that the replay then never adds: every later shard of the round assumed it"""
+
+    def export_adders(self):
+        k = self.start // 131072
+        self.announced = getattr(self, "announced", set()) | {1000 + k, 5000 + k}
+        return np.array(sorted(self.announced), dtype=np.uint32)
+
 
 def _shard_rank_main(rank, world, port, outdir, nseg, total):
     sys.path.insert(0, ROOT)
@@ -125,6 +139,52 @@ def _shard_rank_main(rank, world, port, outdir, nseg, total):
              msgs=np.concatenate([m for _, m in mine]).view(np.uint8) if mine else np.zeros(0, np.uint8))
     rd.barrier(torch.device("cpu"))
     dist.destroy_process_group()
+
+
+def _parallel_rank_main(rank, world, port, outdir, nseg, total, boasting, optimistic):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from readsb_amd import dist as rd
+
+    ch, st = (_BoastingChannel() if boasting else _FakeChannel()), {}
+    mine = rd.decode_recording_parallel(ch, total, 131072, get_segment=lambda a, b: 7_000_000 + a,
+                                        get_carry=lambda a: np.full(326, a % 251, dtype=np.uint8) if a else None,
+                                        device=torch.device("cpu"), optimistic=optimistic, stats=st)
+    np.savez(os.path.join(outdir, f"shard{rank}.npz"), k=np.array([k for k, _ in mine]), redone=st["redone"], passes=st["passes"], rounds=st["rounds"],
+             msgs=np.concatenate([m for _, m in mine]).view(np.uint8) if mine else np.zeros(0, np.uint8))
+    rd.barrier(torch.device("cpu"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("boasting,optimistic", [(False, True), (True, True), (False, False)])
+def test_one_recording_parallel_fixed_point(tmp_path, built, boasting, optimistic):
+    """decode_recording_parallel over gloo: every rank replays its shard at once under an assumed starting filter, the ranks compare
+    what was really added and correct.  With honest adder lists the optimistic start is right at once (no shard decoded twice);
+    with lists that announce addresses nobody adds, or from the pessimistic start, shards are decoded again -- and every shard
+    still ends up having seen exactly the earlier shards' addresses."""
+    import readsb_amd
+
+    for world, nseg in ((2, 5), (3, 4)):
+        total = (nseg - 1) * 131072 + 1000
+        out = tmp_path / f"w{world}"
+        out.mkdir()
+        mp.spawn(_parallel_rank_main, args=(world, _free_port(), str(out), nseg, total, boasting, optimistic), nprocs=world, join=True)
+        seen, redone = {}, 0
+        for r in range(world):
+            z = np.load(out / f"shard{r}.npz")
+            msgs = z["msgs"].view(readsb_amd.MSG_DTYPE)
+            assert list(z["k"]) == list(range(r, nseg, world))
+            redone += int(z["redone"])
+            for k, m in zip(z["k"], msgs):
+                seen[int(k)] = m
+            if not boasting and optimistic:
+                assert int(z["passes"]) == int(z["rounds"])  # one check per round, nothing to correct
+        assert sorted(seen) == list(range(nseg))
+        for k in range(nseg):
+            assert int(seen[k]["ts"]) == k * 131072
+            assert int(seen[k]["addr"]) == k  # the filter held exactly the earlier segments' addresses when the shard was (last) replayed
+        assert (redone == 0) == (not boasting and optimistic)
 
 
 def test_one_recording_sharded_over_ranks(tmp_path, built):
