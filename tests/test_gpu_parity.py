@@ -435,6 +435,33 @@ def test_one_recording_in_shards(nranks, seg_blocks, built):
     assert sum(m.size for m in alone) < want.size
 
 
+@pytest.mark.parametrize("nranks,seg_blocks,optimistic", [(2, 3, True), (4, 1, True), (3, 2, False), (4, 1, False)])
+def test_one_recording_in_shards_without_the_ring(nranks, seg_blocks, optimistic, built):
+    """The same recording, every 'rank' replaying its shard at once under an assumed starting filter, corrected where the assumption
+    was wrong (dist.simulate_parallel = the schedule of decode_recording_parallel): the unsharded output bit for bit.  From the
+    pessimistic start ("the earlier shards of the round add nothing") shards MUST be decoded again -- the coupling is real here."""
+    import torch
+
+    from readsb_amd import dist as rd
+    from readsb_amd.synth import Scenario
+
+    sc = Scenario(13 * 131072 + 777, seed=31, frames_per_sec=3000)
+    iq = generate(sc)
+    want, _ = Oracle(fmt="UC8", nfix=1).run_stream(iq)
+    dev_iq = torch.from_numpy(iq).cuda()
+    chs = [readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=seg_blocks * 131072, defer_prune=True) for _ in range(nranks)]
+    st = {}
+    got = rd.simulate_parallel(chs, sc.n_samples, seg_blocks * 131072, get_segment=lambda a, b: dev_iq.data_ptr() + 2 * a,
+                               get_carry=lambda a: iq[a - 326:a] if a else None, optimistic=optimistic, stats=st)
+    assert first_mismatch(want, got.view(REC_DTYPE)) is None
+    if optimistic:
+        assert st["passes"] <= st["rounds"] + 1, st  # the optimistic start is the fixed point in (nearly) every round
+    else:
+        assert st["redone"] >= 1 and st["passes"] > st["rounds"], st
+    for ch in chs:
+        ch.close()
+
+
 def test_records_written_straight_to_pinned_buffer(built):
     """rsb_collect into pinned host memory (what bench.py passes): the emit kernel then writes the records there itself, no
     device -> host copy.  Same list as into pageable memory and as the reference's; several batches, the last one ragged, and
