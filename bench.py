@@ -138,6 +138,74 @@ def launch_ranks(n: int) -> int:
     return rc
 
 
+def shard_recording_bench(args, rank: int, world: int, local_rank: int, dev) -> int:
+    """--shard-recording: one recording decoded by all ranks together (BASELINE configs[3], "one 64 Gsample recording halo-sharded")"""
+    import torch
+
+    import readsb_amd
+    from readsb_amd import dist as rd
+
+    if args.format != "UC8" or args.dcfilter or args.modeac:
+        raise SystemExit("--shard-recording: UC8 without --dcfilter / --modeac (the filter coupling is what this mode is about)")
+    S = args.shard_recording
+    if S % 131072 or S <= 0:
+        raise SystemExit("--shard-recording: a multiple of 131072 samples")
+    seg_n = min(args.segment, args.samples)
+    reps = args.samples // seg_n
+    n = reps * seg_n
+    seg = make_segment(seg_n, seed=rd.channel_seed(0), fmt="UC8", dense=args.dense)  # every rank holds the SAME recording
+    iq = torch.from_numpy(seg).to(dev).repeat(reps, 1).contiguous()
+    torch.cuda.synchronize()
+    base = iq.data_ptr()
+
+    def carry(start):  # the 326 samples before a cut, from the host's copy of the tiled segment
+        if start == 0:
+            return None
+        idx = np.arange(start - 326, start) % seg_n
+        return np.ascontiguousarray(seg[idx])
+
+    K = max(1, args.shard_contexts) if world == 1 else 1
+    chans = [readsb_amd.Channel(fmt="UC8", fix_bits=args.fix_bits, device=local_rank, max_batch_samples=S, queue_div=16 if args.dense else 32, defer_prune=True)
+             for _ in range(K)]
+    cap = max(1 << 16, S // (256 if args.dense else 512))
+
+    def step(st=None):
+        for c in chans:
+            c.reset()
+        if world == 1:
+            return rd.simulate_parallel(chans, n, S, lambda a, b: base + 2 * a, carry, cap=cap, stats=st)
+        mine = rd.decode_recording_parallel(chans[0], n, S, lambda a, b: base + 2 * a, carry, dev, cap=cap, stats=st)
+        return np.concatenate([m for _, m in mine]) if mine else np.zeros(0, dtype=readsb_amd.MSG_DTYPE)
+
+    for _ in range(args.warmup):
+        step()
+    st = {}
+    rd.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        msgs = step(st)
+    rd.barrier(dev)
+    dt = rd.max_over_ranks(time.perf_counter() - t0, dev)
+    # outside the timed region: all ranks' lists merged by timestamp = the unsharded decode of the recording by one channel (rank 0)
+    merged = rd.merge_channels(msgs, dev) if world > 1 else msgs
+    check = "n/a"
+    if rank == 0:
+        one = readsb_amd.Channel(fmt="UC8", fix_bits=args.fix_bits, device=local_rank, max_batch_samples=n, queue_div=16 if args.dense else 32)
+        one.submit(base, n, torch.cuda.current_stream().cuda_stream)
+        want = one.collect(max(1 << 16, n // (256 if args.dense else 512)))
+        check = "sharded-equals-unsharded" if want.size == merged.size and want.tobytes() == merged.tobytes() else f"SHARD-MISMATCH {want.size} != {merged.size}"
+        print(json.dumps({
+            "metric": "Msamples/s demod+CRC (UC8 @2.4MS/s)", "value": n * args.steps / dt / 1e6, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16",
+            "data": "synthetic",
+            "config": {"workload": "configs[3], second form: ONE synthetic UC8 recording cut at multiples of 131072 samples, segments round-robin over the ranks "
+                                   "with 326-sample halos, ICAO filter coupling as a fixed point over the shards",
+                       "recording_samples": n, "segment_samples": S, "segments": -(-n // S), "ranks": world, "contexts_on_one_gpu": K, "fix_bits": args.fix_bits,
+                       "messages_per_step": int(merged.size), "rounds_per_step": st.get("rounds"), "check_passes_last_step": st.get("passes"),
+                       "shards_decoded_again_last_step_rank0": st.get("redone"), "assumptions_checked_against_the_kept_items_rank0": st.get("checked"), "shard_check": check}}))
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,6 +235,12 @@ def main() -> int:
     ap.add_argument("--channels-per-gpu", type=int, default=1,
                     help="configs[3]: split each GPU's --samples over this many independent receiver channels (own filter, own stream position), "
                          "all submitted before the first is collected")
+    ap.add_argument("--shard-recording", type=int, default=0, metavar="SEGMENT_SAMPLES",
+                    help="configs[3], second form: ONE recording of --samples (the same on every rank) cut into segments of this many samples "
+                         "(a multiple of 131072), segment k decoded by rank k mod N with its 326-sample halo; the ICAO filter coupling is "
+                         "resolved as a fixed point over the shards (readsb_amd/dist.py: decode_recording_parallel).  Strong scaling: the "
+                         "line's value is the recording's samples over the job's time")
+    ap.add_argument("--shard-contexts", type=int, default=1, help="with --shard-recording on ONE GPU: this many contexts take the ranks' roles in turn")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -187,6 +261,12 @@ def main() -> int:
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.shard_recording:
+        rc = shard_recording_bench(args, rank, world, local_rank, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return rc
 
     n = args.samples
     seg_n = min(args.segment, n)

@@ -195,6 +195,12 @@ int rsb_seek(rsb_ctx *ctx, uint64_t stream_pos, const void *carry, int carry_on_
 int rsb_export_adders(rsb_ctx *ctx, uint32_t *out, size_t cap, size_t *n_out);
 /* Widen the prune's superset by these addresses (the other shards' adders).  Does not touch the filter itself. */
 int rsb_superset_add(rsb_ctx *ctx, const uint32_t *addrs, size_t n);
+/* How many of the LAST collected batch's kept items ask the filter about -- or would teach it -- one of `addrs` (n <= 4096)?  0 means
+ * that the batch's messages cannot depend on whether those addresses were in the filter when it was replayed: what a shard needs to
+ * know when the filter it assumed turns out to differ from the true one by these addresses (readsb_amd/dist.py:
+ * decode_recording_parallel).  RSB_ESTATE when that batch was not replayed on the device.  No counterpart in the reference. */
+int rsb_batch_references(rsb_ctx *ctx, const uint32_t *addrs, size_t n, size_t *count);
+
 /* The filter's present contents (both generations, icao_filter.c:97-119), for handing to the next shard's rsb_filter_add. */
 int rsb_filter_export(rsb_ctx *ctx, uint32_t *out, size_t cap, size_t *n_out);
 

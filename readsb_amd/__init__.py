@@ -90,6 +90,7 @@ SYMBOLS = {
     "rsb_seek": (C.c_int, [_VP, C.c_uint64, _VP, C.c_int]),
     "rsb_export_adders": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_superset_add": (C.c_int, [_VP, _VP, _SZ]),
+    "rsb_batch_references": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_filter_export": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_collect": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_collect_begin": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
@@ -281,6 +282,16 @@ class Channel:
     def superset_add(self, addrs: np.ndarray):
         addrs = np.ascontiguousarray(addrs, dtype=np.uint32)
         self._check(self.l.rsb_superset_add(self.h, addrs.ctypes.data if addrs.size else None, addrs.size), "rsb_superset_add")
+
+    def batch_references(self, addrs) -> int:
+        """rsb_batch_references: kept items of the last collected batch that involve one of addrs; -1 = not known (host replay)"""
+        addrs = np.ascontiguousarray(addrs, dtype=np.uint32)
+        n = _SZ()
+        rc = self.l.rsb_batch_references(self.h, addrs.ctypes.data if addrs.size else None, addrs.size, C.byref(n))
+        if rc == -5:  # RSB_ESTATE
+            return -1
+        self._check(rc, "rsb_batch_references")
+        return int(n.value)
 
     def filter_export(self) -> np.ndarray:
         out = np.zeros(2 * 4096, dtype=np.uint32)

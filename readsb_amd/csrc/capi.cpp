@@ -452,6 +452,32 @@ int drop_enqueued_chain(rsb_ctx *c) {
     return RSB_OK;
 }
 
+// a caller's address list on the device (one word of room in front of it for a kernel's counter)
+int upload_addrs(rsb_ctx *c, const uint32_t *addrs, size_t n, uint32_t **dev) {
+    if ((n + 1) * sizeof(uint32_t) > c->addr_list_cap) {
+        if (c->d_addr_list) (void)hipFree(c->d_addr_list);
+        c->d_addr_list = nullptr;
+        c->addr_list_cap = 0;
+        const size_t bytes = (n + 1) * sizeof(uint32_t) * 2 + 4096;
+        HIP_TRY(c, hipMalloc((void **)&c->d_addr_list, bytes));
+        c->addr_list_cap = bytes;
+    }
+    if (n) HIP_TRY(c, hipMemcpy(c->d_addr_list + 1, addrs, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    *dev = c->d_addr_list + 1;
+    return RSB_OK;
+}
+
+// bits of the prune's superset set where it lies (the scans of pending batches set theirs with atomics too: nothing to wait for);
+// on the replay stream, i.e. in front of the prune of whatever is collected next
+int superset_set_bits(rsb_ctx *c, const uint32_t *addrs, size_t n) {
+    uint32_t *dev = nullptr;
+    const int rc = upload_addrs(c, addrs, n, &dev);
+    if (rc != RSB_OK) return rc;
+    HIP_TRY(c, launch_bitmap_set(c->d_bitmap, dev, (uint32_t)n, c->replay_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->replay_stream));  // (the list buffer is reused by the next call)
+    return RSB_OK;
+}
+
 const CrcTables &tables_for(int fix_bits) {
     static const CrcTables t0(0), t1(1), t2(2);
     return fix_bits <= 0 ? t0 : (fix_bits == 1 ? t1 : t2);
@@ -516,7 +542,7 @@ void rsb_destroy(rsb_ctx *c) {
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void *ptrs[] = {c->d_lut, c->d_radial, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
                     c->d_bitmap, c->d_summary, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
-                    c->d_magbuf, c->d_sub_means, c->d_wave_times, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge, c->d_dec_in, c->d_decoded};
+                    c->d_magbuf, c->d_sub_means, c->d_wave_times, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge, c->d_dec_in, c->d_decoded, c->d_addr_list};
     for (rsb_slot &b : c->slots) {
         void *sp[] = {b.d_out, b.d_blk_counts, b.d_blk_start, b.d_blk_base, b.d_new_adders, b.d_items, b.d_region_counts, b.d_region_kept, b.d_region_masks, b.d_chunk_dir, b.d_chunk_kept, b.d_chunk_group, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
         for (void *p : sp)
@@ -567,27 +593,10 @@ int rsb_filter_add_many(rsb_ctx *c, const uint32_t *addrs, size_t n) {
         const int rc = drop_enqueued_chain(c);
         if (rc != RSB_OK) return rc;
     }
-    // the scans of pending batches set bits of the superset with atomics: wait for them before the host touches its words
-    for (rsb_slot &b : c->slots)
-        if (b.pending) HIP_TRY(c, hipEventSynchronize(b.ev[3]));
-    if (n <= 8) {
-        for (size_t i = 0; i < n; ++i) {
-            const uint32_t addr = addrs[i] & 0xffffffu;
-            c->replay.filter().add(addr);
-            uint32_t word = 0;
-            HIP_TRY(c, hipMemcpy(&word, c->d_bitmap + (addr >> 5), 4, hipMemcpyDeviceToHost));
-            word |= 1u << (addr & 31);
-            HIP_TRY(c, hipMemcpy(c->d_bitmap + (addr >> 5), &word, 4, hipMemcpyHostToDevice));
-        }
-    } else {  // one round trip of the whole 2 MiB set instead of two blocking copies per address
-        std::vector<uint32_t> words((1u << 24) / 32);
-        HIP_TRY(c, hipMemcpy(words.data(), c->d_bitmap, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) {
-            const uint32_t addr = addrs[i] & 0xffffffu;
-            c->replay.filter().add(addr);
-            words[addr >> 5] |= 1u << (addr & 31);
-        }
-        HIP_TRY(c, hipMemcpy(c->d_bitmap, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    for (size_t i = 0; i < n; ++i) c->replay.filter().add(addrs[i] & 0xffffffu);
+    {
+        const int rc = superset_set_bits(c, addrs, n);  // (the two blocking 2 MiB copies per call this replaces cost a shard hand-over 1 ms)
+        if (rc != RSB_OK) return rc;
     }
     c->filter_dirty = true;
     return RSB_OK;
@@ -642,6 +651,29 @@ int rsb_seek(rsb_ctx *c, uint64_t stream_pos, const void *carry, int carry_on_de
 
 int rsb_export_adders(rsb_ctx *c, uint32_t *out, size_t cap, size_t *n_out) {
     if (!c || (!out && cap) || !n_out) return RSB_EINVAL;
+    {
+        // the set bits listed on the device (a few hundred addresses instead of 2 MiB across PCIe), behind every pending scan
+        HIP_TRY(c, hipSetDevice(c->cfg.device));
+        hipStream_t s = c->replay_stream;
+        for (rsb_slot &b : c->slots)
+            if (b.pending) HIP_TRY(c, hipStreamWaitEvent(s, b.ev[3], 0));
+        uint32_t *list = (uint32_t *)c->d_sort_temp;
+        const uint32_t room = (uint32_t)std::min<size_t>(c->sort_temp_bytes / sizeof(uint32_t) - 1, 1u << 20);
+        HIP_TRY(c, launch_bitmap_list(c->d_bitmap, list, room, s));
+        uint32_t found = 0;
+        HIP_TRY(c, hipMemcpyAsync(&found, list, sizeof(found), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (found <= room) {
+            *n_out = found;
+            if (found > cap) {
+                c->err = "rsb_export_adders: output buffer too small";
+                return RSB_EOVERFLOW;
+            }
+            if (found) HIP_TRY(c, hipMemcpy(out, list + 1, found * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            std::sort(out, out + found);
+            return RSB_OK;
+        }
+    }
     std::vector<uint32_t> words;
     const int rc = fetch_bitmap(c, words);
     if (rc != RSB_OK) return rc;
@@ -660,15 +692,31 @@ int rsb_export_adders(rsb_ctx *c, uint32_t *out, size_t cap, size_t *n_out) {
 }
 
 int rsb_superset_add(rsb_ctx *c, const uint32_t *addrs, size_t n) {
-    if (!c || (!addrs && n)) return RSB_EINVAL;
+    if (!c || (!addrs && n) || n > 0xffffffffull) return RSB_EINVAL;
     if (n == 0) return RSB_OK;
-    std::vector<uint32_t> words;
-    int rc = drop_enqueued_chain(c);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int rc = drop_enqueued_chain(c);
     if (rc != RSB_OK) return rc;
-    rc = fetch_bitmap(c, words);
+    return superset_set_bits(c, addrs, n);
+}
+
+int rsb_batch_references(rsb_ctx *c, const uint32_t *addrs, size_t n, size_t *count) {
+    if (!c || (!addrs && n) || !count || n > 4096) return RSB_EINVAL;
+    *count = 0;
+    if (!c->last_items_info) {
+        c->err = "rsb_batch_references: the last collected batch was not replayed on the device (its kept items are not at hand)";
+        return RSB_ESTATE;
+    }
+    if (n == 0 || c->last_items_n == 0) return RSB_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    uint32_t *dev = nullptr;
+    const int rc = upload_addrs(c, addrs, n, &dev);
     if (rc != RSB_OK) return rc;
-    for (size_t i = 0; i < n; ++i) words[(addrs[i] & 0xffffffu) >> 5] |= 1u << (addrs[i] & 31);
-    HIP_TRY(c, hipMemcpy(c->d_bitmap, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, launch_items_reference(c->last_items_info, c->last_items_n, dev, (uint32_t)n, dev - 1, c->replay_stream));
+    uint32_t hits = 0;
+    HIP_TRY(c, hipMemcpyAsync(&hits, dev - 1, sizeof(hits), hipMemcpyDeviceToHost, c->replay_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->replay_stream));
+    *count = hits;
     return RSB_OK;
 }
 
@@ -906,6 +954,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     ++c->collected;
     c->last_n = b.pending_n;
     c->last_list_dev = nullptr;
+    c->last_items_info = nullptr;
     c->last_g0 = b.g0;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     // everything from here on runs on the context's own stream, behind this batch's scan and beside the next batch's
@@ -1147,6 +1196,10 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     }
 #endif
 
+    if (on_device && chain_ran && c->run_modes) {  // the kept items the replay worked on stay where they are until this slot is scanned again
+        c->last_items_info = b.chain_r.info;
+        c->last_items_n = b.chain_r.n_items;
+    }
     st.samples_processed += b.pending_n;
     st.gated_offsets += cnt[kCntGated];
     st.general_strips += cnt[kCntGeneralStrips];

@@ -115,6 +115,10 @@ struct rsb_ctx {
     rsb_message *d_dec_in = nullptr;
     rsb_decoded *d_decoded = nullptr;
     size_t dec_in_cap = 0, decoded_cap = 0;
+    uint32_t *d_addr_list = nullptr;             // address lists from the caller (superset / filter additions, reference queries), grown on demand
+    size_t addr_list_cap = 0;
+    const uint32_t *last_items_info = nullptr;   // the kept items of the last collected batch (device replay): what rsb_batch_references asks
+    uint32_t last_items_n = 0;
     const rsb_message *last_list_dev = nullptr;  // collect_impl: where the batch's final list lies on the device (nullptr: only on the host)
     uint64_t last_g0 = 0;                        // ... and the batch's stream position
     static constexpr uint32_t kNewAddersCap = 8192;

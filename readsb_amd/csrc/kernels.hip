@@ -3332,6 +3332,46 @@ hipError_t launch_filter_update(uint32_t *t0, uint32_t *t1, const uint32_t *stal
     return hipGetLastError();
 }
 
+// ---- the adder bitmap (the prune's superset) worked on where it lies: 2 MiB that used to cross PCIe for every change or export
+__global__ __launch_bounds__(kThreads) void k_bitmap_set(uint32_t *bitmap, const uint32_t *addrs, uint32_t n) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) atomicOr(&bitmap[(addrs[i] & 0xffffffu) >> 5], 1u << (addrs[i] & 31u));
+}
+// out[0] = number of set bits, out[1 ..] = their addresses (in no particular order; the first cap are stored)
+__global__ __launch_bounds__(kThreads) void k_bitmap_list(const uint32_t *__restrict__ bitmap, uint32_t *out, uint32_t cap) {
+    for (uint32_t w = blockIdx.x * kThreads + threadIdx.x; w < (1u << 24) / 32; w += gridDim.x * kThreads)
+        for (uint32_t x = bitmap[w]; x; x &= x - 1) {
+            const uint32_t slot = atomicAdd(out, 1u);
+            if (slot < cap) out[1 + slot] = (w << 5) | (uint32_t)__builtin_ctz(x);
+        }
+}
+// how many of a batch's kept items ask the filter about (or would teach it) one of the given addresses
+__global__ __launch_bounds__(kThreads) void k_items_reference(const uint32_t *__restrict__ info, uint32_t n, const uint32_t *__restrict__ addrs, uint32_t na,
+                                                               uint32_t *count) {
+    uint32_t hits = 0;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const uint32_t v = item_value(info[i]);
+        for (uint32_t k = 0; k < na; ++k) hits += addrs[k] == v ? 1u : 0u;
+    }
+    if (hits) atomicAdd(count, hits);
+}
+hipError_t launch_bitmap_set(uint32_t *bitmap, const uint32_t *addrs_dev, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_bitmap_set, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, s, bitmap, addrs_dev, n);
+    return hipGetLastError();
+}
+hipError_t launch_bitmap_list(const uint32_t *bitmap, uint32_t *out, uint32_t cap, hipStream_t s) {
+    const hipError_t e = hipMemsetAsync(out, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_bitmap_list, dim3(512), dim3(kThreads), 0, s, bitmap, out, cap);
+    return hipGetLastError();
+}
+hipError_t launch_items_reference(const uint32_t *info, uint32_t n, const uint32_t *addrs_dev, uint32_t na, uint32_t *count, hipStream_t s) {
+    const hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    if (n && na) hipLaunchKernelGGL(k_items_reference, dim3(item_grid(n)), dim3(kThreads), 0, s, info, n, addrs_dev, na, count);
+    return hipGetLastError();
+}
+
 hipError_t launch_filter_rebuild(uint32_t *t0, uint32_t *t1, const uint32_t *addrs_dev, uint32_t n, hipStream_t s) {
     hipError_t e = hipMemsetAsync(t0, 0xff, sizeof(uint32_t) << 24, s);
     if (e != hipSuccess) return e;

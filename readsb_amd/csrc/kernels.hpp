@@ -201,6 +201,9 @@ hipError_t launch_decode_fields(const rsb_message *msgs_dev, uint32_t n, uint64_
 hipError_t launch_wire_offsets(const WireArgs &w, void *temp, size_t temp_bytes, hipStream_t s);
 hipError_t launch_wire_write(const WireArgs &w, hipStream_t s);
 // first-add tables := "never" everywhere, 0 for address 0 and the n given addresses
+hipError_t launch_bitmap_set(uint32_t *bitmap, const uint32_t *addrs_dev, uint32_t n, hipStream_t s);
+hipError_t launch_bitmap_list(const uint32_t *bitmap, uint32_t *out, uint32_t cap, hipStream_t s);
+hipError_t launch_items_reference(const uint32_t *info, uint32_t n, const uint32_t *addrs_dev, uint32_t na, uint32_t *count, hipStream_t s);
 hipError_t launch_filter_rebuild(uint32_t *t0, uint32_t *t1, const uint32_t *addrs_dev, uint32_t n, hipStream_t s);
 // the same without refilling the tables: stale_dev[0..n_stale) are the entries that are 0 now and go back to "never" first
 hipError_t launch_filter_update(uint32_t *t0, uint32_t *t1, const uint32_t *stale_dev, uint32_t n_stale, const uint32_t *addrs_dev, uint32_t n, hipStream_t s);

@@ -216,6 +216,10 @@ def simulate_sharded(chs, total_samples: int, segment_samples: int, get_segment,
 # the shards (shard 0's starting filter is always exact) the loop ends after at most `world` passes with exactly the serial result;
 # with the optimistic start it normally ends after the first.  Prune, replay, emit and the record copy all run in parallel; what is
 # serial is two small all-gathers per round.
+# A wrong assumption is the rule, not the exception, on long shards (noise alone produces a dozen clean-looking DF11 per Gsample, and
+# one in six of them lies inside another message's skip window and is never looked at): so a rank first asks whether the difference
+# can matter at all -- rsb_batch_references: does any kept item of its shard involve one of the addresses by which the assumed and
+# the true filter differ? -- and decodes again only if one does.
 
 def _gather_lists_u32(mine: np.ndarray, device: torch.device) -> list[np.ndarray]:
     """variable-length all-gather of uint32 lists -> one list per rank (on every rank)"""
@@ -239,7 +243,8 @@ class _Shard:
     def __init__(self, ch, cap):
         self.ch, self.cap = ch, cap
         self.seen = np.zeros(0, dtype=np.uint32)  # the adder list of this rank's context so far (it only grows)
-        self.redone = 0
+        self.redone = self.checked = 0
+        self.pre = np.zeros(0, dtype=np.uint32)
 
     def scan(self, start, nsamples, dev_ptr, carry):
         self.args = (start, nsamples, dev_ptr, carry)
@@ -249,12 +254,22 @@ class _Shard:
         return new
 
     def replay(self, assumed: np.ndarray, superset: np.ndarray):
-        """collect under the assumption that the filter holds exactly `assumed` -> (messages, addresses this shard added)"""
+        """collect with the filter holding `assumed` (and whatever an earlier unconfirmed assumption left in this context)
+        -> (messages, addresses this shard added); self.pre = the filter's contents the replay really started from"""
         self.ch.superset_add(superset)
-        have = self.ch.filter_export()
-        self.ch.filter_add_many(np.setdiff1d(assumed, have))
+        self.ch.filter_add_many(np.setdiff1d(assumed, self.ch.filter_export()))
+        self.pre = self.ch.filter_export()
         msgs = self.ch.collect(self.cap).copy()
-        return msgs, np.setdiff1d(self.ch.filter_export(), assumed)
+        return msgs, np.setdiff1d(self.ch.filter_export(), self.pre)
+
+    def must_redo(self, true_in: np.ndarray) -> bool:
+        """could the shard's result differ had it started from true_in instead of self.pre?"""
+        diff = np.setxor1d(self.pre, true_in)
+        if diff.size == 0:
+            return False
+        self.checked += 1
+        refs = self.ch.batch_references(diff) if diff.size <= 4096 and hasattr(self.ch, "batch_references") else -1
+        return refs != 0
 
     def redo(self, true_filter: np.ndarray, superset: np.ndarray):
         """the assumption was wrong: the shard again from a context that holds the true filter (rsb_reset forgets the optimistic one)"""
@@ -293,9 +308,8 @@ def decode_recording_parallel(ch, total_samples: int, segment_samples: int, get_
             passes += 1
             adds = _gather_lists_u32(added, device)
             true_in = np.unique(np.concatenate([f_in] + adds[:rank]))
-            wrong = active and not np.array_equal(true_in, assumed)
+            wrong = active and me.must_redo(true_in)
             if wrong:
-                assumed = true_in
                 msgs, added = me.redo(true_in, superset)
             if max_over_ranks(1.0 if wrong else 0.0, device) == 0.0:
                 break
@@ -303,7 +317,7 @@ def decode_recording_parallel(ch, total_samples: int, segment_samples: int, get_
         if active:
             mine.append((k, msgs))
     if stats is not None:
-        stats.update(redone=me.redone, passes=passes, rounds=(nseg + n - 1) // n)
+        stats.update(redone=me.redone, checked=me.checked, passes=passes, rounds=(nseg + n - 1) // n)
     return mine
 
 
@@ -330,8 +344,7 @@ def simulate_parallel(chs, total_samples: int, segment_samples: int, get_segment
             any_wrong = False
             for r in range(len(ks)):  # (every 'rank' decides from the same gathered lists, as the ranks of a job do)
                 true_in = np.unique(np.concatenate([f_in] + adds[:r]))
-                if not np.array_equal(true_in, assumed[r]):
-                    assumed[r] = true_in
+                if shards[r].must_redo(true_in):
                     results[r] = shards[r].redo(true_in, superset)
                     any_wrong = True
             if not any_wrong:
@@ -339,5 +352,5 @@ def simulate_parallel(chs, total_samples: int, segment_samples: int, get_segment
         f_in = np.unique(np.concatenate([f_in] + [a for _, a in results]))
         out.extend(m for m, _ in results)
     if stats is not None:
-        stats.update(redone=sum(s.redone for s in shards), passes=passes, rounds=(nseg + n - 1) // n)
+        stats.update(redone=sum(s.redone for s in shards), checked=sum(s.checked for s in shards), passes=passes, rounds=(nseg + n - 1) // n)
     return np.concatenate(out) if out else np.zeros(0, dtype=MSG_DTYPE)

@@ -24,7 +24,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, outdir):
+def _rank_main(rank, world, port, outdir, parallel=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -35,9 +35,9 @@ def _rank_main(rank, world, port, outdir):
     iq = generate(Scenario(N_SAMPLES, seed=SEED, frames_per_sec=3000))  # every rank reads "the same file"
     dev_iq = torch.from_numpy(iq).cuda()
     ch = readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=SEG_BLOCKS * 131072, defer_prune=True)
-    mine = rd.decode_recording_sharded(ch, N_SAMPLES, SEG_BLOCKS * 131072,
-                                       get_segment=lambda a, b: dev_iq.data_ptr() + 2 * a,
-                                       get_carry=lambda a: iq[a - 326:a] if a else None, device=torch.device("cpu"))
+    decode = rd.decode_recording_parallel if parallel else rd.decode_recording_sharded
+    mine = decode(ch, N_SAMPLES, SEG_BLOCKS * 131072, get_segment=lambda a, b: dev_iq.data_ptr() + 2 * a,
+                  get_carry=lambda a: iq[a - 326:a] if a else None, device=torch.device("cpu"))
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), k=np.array([k for k, _ in mine]), sizes=np.array([m.size for _, m in mine]),
              msgs=np.concatenate([m for _, m in mine]).view(np.uint8))
     ch.close()
@@ -45,13 +45,14 @@ def _rank_main(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_recording(tmp_path, built):
+@pytest.mark.parametrize("parallel", [False, True], ids=["filter-ring", "fixed-point"])
+def test_two_ranks_one_recording(tmp_path, built, parallel):
     import readsb_amd
     from oracle.oracle import Oracle, REC_DTYPE, first_mismatch
     from readsb_amd.synth import Scenario, generate
 
     world = 2
-    mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path), parallel), nprocs=world, join=True)
     parts = {}
     for r in range(world):
         z = np.load(tmp_path / f"rank{r}.npz")
