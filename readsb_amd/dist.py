@@ -240,8 +240,10 @@ def _gather_lists_u32(mine: np.ndarray, device: torch.device) -> list[np.ndarray
 class _Shard:
     """one rank's side of the fixed point (also driven directly by simulate_parallel)"""
 
-    def __init__(self, ch, cap):
-        self.ch, self.cap = ch, cap
+    def __init__(self, ch, cap, out=None):
+        # out (optional): a caller-owned record buffer (pinned memory) for ALL of this rank's segments of the job; the message lists
+        # returned are then views into it, and nothing is copied on the host
+        self.ch, self.cap, self.out, self.pos, self.last = ch, cap, out, 0, (0, 0)
         self.seen = np.zeros(0, dtype=np.uint32)  # the adder list of this rank's context so far (it only grows)
         self.redone = self.checked = 0
         self.pre = np.zeros(0, dtype=np.uint32)
@@ -259,8 +261,18 @@ class _Shard:
         self.ch.superset_add(superset)
         self.ch.filter_add_many(np.setdiff1d(assumed, self.ch.filter_export()))
         self.pre = self.ch.filter_export()
-        msgs = self.ch.collect(self.cap).copy()
+        msgs = self._collect()
         return msgs, np.setdiff1d(self.ch.filter_export(), self.pre)
+
+    def _collect(self, again=False):
+        if self.out is None:
+            return self.ch.collect(self.cap).copy()
+        if again:
+            self.pos = self.last[0]  # the shard decoded again: over its first list
+        msgs = self.ch.collect(out=self.out[self.pos:self.pos + self.cap])
+        self.last = (self.pos, msgs.size)
+        self.pos += msgs.size
+        return msgs
 
     def must_redo(self, true_in: np.ndarray) -> bool:
         """could the shard's result differ had it started from true_in instead of self.pre?"""
@@ -277,11 +289,14 @@ class _Shard:
         self.ch.reset()
         self.ch.filter_add_many(true_filter)
         self.seen = shard_scan(self.ch, *self.args)
-        return self.replay(true_filter, superset)
+        self.ch.superset_add(superset)
+        self.pre = self.ch.filter_export()
+        msgs = self._collect(again=True)
+        return msgs, np.setdiff1d(self.ch.filter_export(), self.pre)
 
 
 def decode_recording_parallel(ch, total_samples: int, segment_samples: int, get_segment, get_carry, device: torch.device, cap: int = 1 << 20,
-                              optimistic: bool = True, stats: dict | None = None):
+                              optimistic: bool = True, stats: dict | None = None, out=None):
     """decode_recording_sharded's result without its serial ring (see above).  ch: this rank's Channel, created with defer_prune=True.
     optimistic=False starts from "the earlier shards of the round add nothing" (tests: forces the correction passes).
     -> list of (segment index, messages) of this rank's segments."""
@@ -290,7 +305,7 @@ def decode_recording_parallel(ch, total_samples: int, segment_samples: int, get_
     assert segment_samples % BLOCK == 0 and segment_samples > 0
     rank, n = world()
     nseg = (total_samples + segment_samples - 1) // segment_samples
-    me = _Shard(ch, cap)
+    me = _Shard(ch, cap, out)
     f_in = np.zeros(0, dtype=np.uint32)  # the exact filter at the start of the round, the same on every rank
     mine, passes = [], 0
     for j in range((nseg + n - 1) // n):
@@ -322,11 +337,11 @@ def decode_recording_parallel(ch, total_samples: int, segment_samples: int, get_
 
 
 def simulate_parallel(chs, total_samples: int, segment_samples: int, get_segment, get_carry, cap: int = 1 << 20, optimistic: bool = True,
-                      stats: dict | None = None) -> np.ndarray:
+                      stats: dict | None = None, outs=None, join: bool = True):
     """decode_recording_parallel's schedule with len(chs) channels in one process and no torch.distributed: 'rank' r is chs[r]."""
     n = len(chs)
     nseg = (total_samples + segment_samples - 1) // segment_samples
-    shards = [_Shard(ch, cap) for ch in chs]
+    shards = [_Shard(ch, cap, outs[r] if outs else None) for r, ch in enumerate(chs)]
     f_in = np.zeros(0, dtype=np.uint32)
     out, passes = [], 0
     for j in range((nseg + n - 1) // n):
@@ -353,4 +368,6 @@ def simulate_parallel(chs, total_samples: int, segment_samples: int, get_segment
         out.extend(m for m, _ in results)
     if stats is not None:
         stats.update(redone=sum(s.redone for s in shards), checked=sum(s.checked for s in shards), passes=passes, rounds=(nseg + n - 1) // n)
+    if not join:
+        return out  # the segments' lists in stream order (views into `outs` when given)
     return np.concatenate(out) if out else np.zeros(0, dtype=MSG_DTYPE)
