@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -243,10 +244,9 @@ int enqueue_readbacks(rsb_ctx *c, rsb_slot &b, const ReplayArgs &r, hipStream_t 
 // left in the batch's counters, and replay_finish checks what the host could not know beforehand).
 // direct_out (optional, RSB_EMIT_DIRECT=1): the caller's record buffer.  If the device can address it (pinned host memory), the
 // emit kernel writes the records there itself and no device -> host copy follows.
-int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_device, hipStream_t s, rsb_message *direct_out = nullptr, size_t direct_cap = 0) {
+// the replay's arguments for the slot's pending batch (the tables t_cur / t_next are the caller's to set: the mirror may swap them)
+void fill_replay_args(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_device) {
     const BatchArgs &a = b.pending_args;
-    int rc;
-    if (c->filter_dirty && (rc = mirror_filter(c, s)) != RSB_OK) return rc;
     ReplayArgs &r = b.chain_r;
     std::memset(&r, 0, sizeof(r));
     r.keys = a.skeys[c->sorted_buf];
@@ -272,6 +272,16 @@ int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devi
     b.chain_enqueued = true;
     b.chain_count_on_device = count_on_device;
     b.chain_to_host = false;
+    b.chain_folded = false;
+    b.time_from = nullptr;
+}
+
+int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_device, hipStream_t s, rsb_message *direct_out = nullptr, size_t direct_cap = 0) {
+    const BatchArgs &a = b.pending_args;
+    int rc;
+    if (c->filter_dirty && (rc = mirror_filter(c, s)) != RSB_OK) return rc;
+    fill_replay_args(c, b, n_items, count_on_device);
+    ReplayArgs &r = b.chain_r;
     // A record copy that rsb_collect_begin left in flight reads the d_out of ITS slot; this chain writes this slot's.  The same
     // slot only on one-slot contexts (dc_filter, SC16Q11 table): begin(k), submit(k + 1), prepare(k + 1) -- the chain then waits
     // on the device for the copy, the host does not.
@@ -375,7 +385,9 @@ int replay_finish(rsb_ctx *c, rsb_slot &b, hipStream_t s, uint32_t cnt[kCntCount
         std::memcpy(cnt, pin + 1, kCntCount * sizeof(uint32_t));
         std::memcpy(c->h_blk_counts.data(), pin + 1 + kCntCount, r.nblocks * sizeof(uint32_t));
     }
-    HIP_TRY(c, launch_replay_fold(r, s));  // the batch's new members become "in the filter before the next batch" (asynchronous)
+    // the batch's new members become "in the filter before the next batch" (asynchronous; a chain for many channels has done it
+    // on the device for the channels whose first round was the fixed point)
+    if (!(emitted && b.chain_folded)) HIP_TRY(c, launch_replay_fold(r, s));
     // The tables answer "is this address in the filter" as a set.  The reference's open-addressing table does
     // the same until it is full (icao_filter.c:76-79, 101-106): stay well clear of that, else replay on the host.
     const uint32_t nnew = cnt[kCntNewAdders];
@@ -536,6 +548,10 @@ void rsb_destroy(rsb_ctx *c) {
     if (c->h_addr_upload) (void)hipHostFree(c->h_addr_upload);
     if (c->h_many_args) (void)hipHostFree(c->h_many_args);
     if (c->d_many_args) (void)hipFree(c->d_many_args);
+    if (c->h_chain_args) (void)hipHostFree(c->h_chain_args);
+    if (c->d_chain_args) (void)hipFree(c->d_chain_args);
+    if (c->h_chain_back) (void)hipHostFree(c->h_chain_back);
+    if (c->d_chain_back) (void)hipFree(c->d_chain_back);
     for (hipEvent_t ev : c->many_args_read)
         if (ev) (void)hipEventDestroy(ev);
     if (c->addr_upload_done) (void)hipEventDestroy(c->addr_upload_done);
@@ -734,6 +750,8 @@ int rsb_filter_export(rsb_ctx *c, uint32_t *out, size_t cap, size_t *n_out) {
 
 // a batch onto the caller's stream in three parts, so that rsb_submit_many can put ONE scan launch between the first and the last
 // part of all its channels
+static std::atomic<uint64_t> g_submit_seq{0};  // orders the ev[3] records of all contexts (rsb_collect_many: which of one stream's is the last)
+
 static int enqueue_before_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, hipStream_t s, bool record_start = true) {
     // (one-slot contexts: a record copy still in flight may read this slot's item buffer -- a list merged with Mode A/C messages)
     if (c->copy_in_flight && c->copy_slot == &b) HIP_TRY(c, hipStreamWaitEvent(s, c->copy_done, 0));
@@ -794,6 +812,7 @@ static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint6
         c->carry_valid[k] = 1;
     }
     HIP_TRY(c, hipEventRecord(b.ev[3], s));
+    b.submit_seq = ++g_submit_seq;
     b.pending = true;
     b.pending_n = nsamples;
     b.pending_stream = s;
@@ -958,7 +977,8 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     c->last_g0 = b.g0;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     // everything from here on runs on the context's own stream, behind this batch's scan and beside the next batch's
-    hipStream_t s = c->replay_stream;
+    // (rsb_collect_many: the channels' shared chain ran on one stream, and whatever is left to do for this channel follows it there)
+    hipStream_t s = c->chain_stream ? c->chain_stream : c->replay_stream;
     HIP_TRY(c, hipStreamWaitEvent(s, b.ev[3], 0));
     if (!b.chain_enqueued) HIP_TRY(c, hipEventRecord(b.rev[0], s));  // (collect_ahead has recorded it otherwise)
     if (c->run_modes && !b.pruned && !b.chain_enqueued) {  // against the superset as it is now (the caller may have widened it)
@@ -1125,7 +1145,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
                 HIP_TRY(c, hipEventRecord(c->copy_done, c->copy_stream));
                 c->copy_slot = &b;
             }
-            collect_ahead(c);
+            if (!c->chain_stream) collect_ahead(c);
             if (c->defer_copy_wait && ncopy)
                 c->copy_in_flight = true;  // rsb_collect_begin: the caller comes back with rsb_collect_wait
             else
@@ -1151,9 +1171,11 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     c->timing.prune_ms = 0;
     (void)hipEventElapsedTime(&c->timing.modeac_ms, b.ev[2], b.ev[3]);
     (void)hipEventElapsedTime(&c->timing.total_ms, b.ev[0], b.ev[3]);
-    (void)hipEventElapsedTime(&c->timing.prune_ms, b.rev[0], b.rev[1]);  // prune (+ the radix sort in the fallback cases)
+    const rsb_slot &tb = b.time_from ? *b.time_from : b;  // (a chain shared by many channels: its times, the same for every channel)
+    (void)hipEventElapsedTime(&c->timing.prune_ms, tb.rev[0], tb.rev[1]);  // prune (+ the radix sort in the fallback cases)
     c->timing.sort_ms = 0;
-    (void)hipEventElapsedTime(&ms, b.rev[1], b.rev[2]);
+    (void)hipEventElapsedTime(&ms, tb.rev[1], tb.rev[2]);
+    b.time_from = nullptr;
     c->timing.device_replay_ms = on_device ? ms : 0.0f;
     if (!on_device) c->timing.prune_ms += ms;  // the candidate re-slice belongs to the prune stage of the host path
     c->timing.total_ms += c->timing.sort_ms + ms;
@@ -1448,11 +1470,158 @@ int rsb_submit_many(rsb_ctx *const *ctx, size_t nch, const void *const *iq_dev, 
     return RSB_OK;
 }
 
+// All channels' prune / replay / emit chains as ONE chain of launches (kernels.hip "the *_many forms") on one stream and one host
+// wait: possible when every channel's batch is the usual kind (chain_needs_no_host), nothing of it is enqueued yet, and the channels
+// are distinct contexts of one device and one sample format.
+static bool one_chain_possible(rsb_ctx *const *ctx, size_t nch) {
+    if (nch < 2 || std::getenv("RSB_NO_CHAIN_MANY")) return false;
+    const rsb_ctx *c0 = ctx[0];
+    for (size_t i = 0; i < nch; ++i) {
+        rsb_ctx *c = ctx[i];
+        if (c->cfg.device != c0->cfg.device || c->cfg.input_format != c0->cfg.input_format || !c->any_pending()) return false;
+        const rsb_slot &b = c->collect_slot();
+        if (!b.pending || b.chain_enqueued || b.pruned || !chain_needs_no_host(c, b) || b.pending_args.fmt != ctx[0]->collect_slot().pending_args.fmt) return false;
+        for (size_t k = 0; k < i; ++k)
+            if (ctx[k] == c) return false;
+    }
+    return true;
+}
+
+// enqueues the shared chain and waits for it; afterwards every channel's slot looks as if its own chain had been enqueued and
+// had run (b.chain_enqueued, the readbacks in b.h_pin): rsb_collect_begin takes it from there, on the shared stream
+static int run_one_chain(rsb_ctx *const *ctx, size_t nch) {
+    rsb_ctx *c0 = ctx[0];
+    hipStream_t s = c0->replay_stream;
+    HIP_TRY(c0, hipSetDevice(c0->cfg.device));
+    ChainDims d;
+    std::memset(&d, 0, sizeof(d));
+    d.nch = (uint32_t)nch;
+    for (size_t i = 0; i < nch; ++i) {
+        const int rc = rsb_collect_wait(ctx[i]);  // (a record copy left in flight reads the d_out this chain writes, on one-slot contexts)
+        if (rc != RSB_OK) return rc;
+    }
+    if (nch > c0->chain_args_cap) {
+        if (c0->d_chain_args) (void)hipFree(c0->d_chain_args);
+        if (c0->h_chain_args) (void)hipHostFree(c0->h_chain_args);
+        c0->d_chain_args = nullptr;
+        c0->h_chain_args = nullptr;
+        c0->chain_args_cap = 0;
+        HIP_TRY(c0, hipMalloc((void **)&c0->d_chain_args, nch * sizeof(ChainArgs)));
+        HIP_TRY(c0, hipHostMalloc((void **)&c0->h_chain_args, nch * sizeof(ChainArgs), hipHostMallocDefault));
+        c0->chain_args_cap = nch;
+    }
+    // behind every channel's scan (channels submitted on one stream: behind the last one's)
+    bool one_stream = true;
+    for (size_t i = 1; i < nch; ++i) one_stream = one_stream && ctx[i]->collect_slot().pending_stream == ctx[0]->collect_slot().pending_stream;
+    size_t last = 0;
+    for (size_t i = 1; i < nch; ++i)
+        if (ctx[i]->collect_slot().submit_seq > ctx[last]->collect_slot().submit_seq) last = i;
+    for (size_t i = 0; i < nch; ++i)
+        if (!one_stream || i == last) HIP_TRY(ctx[i], hipStreamWaitEvent(s, ctx[i]->collect_slot().ev[3], 0));
+    rsb_slot &b0 = c0->collect_slot();
+    HIP_TRY(c0, hipEventRecord(b0.rev[0], s));
+    for (size_t i = 0; i < nch; ++i) {
+        rsb_ctx *c = ctx[i];
+        rsb_slot &b = c->collect_slot();
+        int rc;
+        if (c->filter_dirty && (rc = mirror_filter(c, s)) != RSB_OK) return rc;
+        b.pruned = true;
+        b.pruned_in_order = true;  // (chain_needs_no_host: prune_is_ordered)
+        c->sorted_buf = 0;
+        fill_replay_args(c, b, kept_items_bound(c, b), true);
+        ReplayArgs &r = b.chain_r;
+        r.t_cur = c->d_first_add[c->first_cur];
+        r.t_next = c->d_first_add[c->first_cur ^ 1];
+        b.chain_folded = true;
+        b.time_from = &b0;
+        b.h_pin[0] = 0;
+        c0->h_chain_args[i].a = b.pending_args;
+        c0->h_chain_args[i].r = r;
+        const BatchArgs &a = b.pending_args;
+        if (a.n) {
+            d.max_regions = std::max(d.max_regions, a.n_regions);
+            d.max_chunks = std::max(d.max_chunks, a.n_chunks);
+            d.max_items = std::max(d.max_items, r.n_items);
+            d.max_nblocks = std::max(d.max_nblocks, r.nblocks);
+            d.any_summary = d.any_summary || a.adder_summary != nullptr;
+        }
+    }
+    const uint32_t stride = 1 + kCntCount + d.max_nblocks + 2 * rsb_ctx::kPinAdders;
+    if ((size_t)stride * nch > c0->chain_back_cap) {
+        if (c0->d_chain_back) (void)hipFree(c0->d_chain_back);
+        if (c0->h_chain_back) (void)hipHostFree(c0->h_chain_back);
+        c0->d_chain_back = nullptr;
+        c0->h_chain_back = nullptr;
+        c0->chain_back_cap = 0;
+        const size_t words = (size_t)stride * nch + 4096;
+        HIP_TRY(c0, hipMalloc((void **)&c0->d_chain_back, words * sizeof(uint32_t)));
+        HIP_TRY(c0, hipHostMalloc((void **)&c0->h_chain_back, words * sizeof(uint32_t), hipHostMallocDefault));
+        c0->chain_back_cap = words;
+    }
+    if (d.max_nblocks) {
+        HIP_TRY(c0, hipMemcpyAsync(c0->d_chain_args, c0->h_chain_args, nch * sizeof(ChainArgs), hipMemcpyHostToDevice, s));
+        HIP_TRY(c0, launch_chain_prune_many(c0->d_chain_args, d, s));
+        HIP_TRY(c0, hipEventRecord(b0.rev[1], s));
+        HIP_TRY(c0, launch_chain_replay_many(c0->collect_slot().pending_args.fmt, c0->d_chain_args, d, c0->d_chain_back, stride, rsb_ctx::kPinAdders, s));
+        HIP_TRY(c0, hipMemcpyAsync(c0->h_chain_back, c0->d_chain_back, (size_t)stride * nch * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    } else {
+        HIP_TRY(c0, hipEventRecord(b0.rev[1], s));
+    }
+    HIP_TRY(c0, hipEventRecord(b0.rev[2], s));
+    HIP_TRY(c0, hipStreamSynchronize(s));
+    for (size_t i = 0; i < nch && d.max_nblocks; ++i) {  // every channel's part to where replay_finish looks for it
+        rsb_ctx *c = ctx[i];
+        rsb_slot &b = c->collect_slot();
+        const uint32_t *src = c0->h_chain_back + (size_t)i * stride;
+        const uint32_t nblk = b.chain_r.nblocks;
+        std::memcpy(b.h_pin, src, (1 + kCntCount) * sizeof(uint32_t));
+        std::memcpy(b.h_pin + 1 + kCntCount, src + 1 + kCntCount, nblk * sizeof(uint32_t));
+        const uint32_t nadd = std::min<uint32_t>(src[1 + kCntNewAdders], rsb_ctx::kPinAdders);
+        std::memcpy(b.h_pin + 1 + kCntCount + c->nblocks_cap, src + 1 + kCntCount + d.max_nblocks, (size_t)nadd * sizeof(uint2));
+    }
+    return RSB_OK;
+}
+
 int rsb_collect_many(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, const size_t *cap, size_t *n_out) {
     if (!ctx || !out || !cap || !n_out) return RSB_EINVAL;
     for (size_t i = 0; i < nch; ++i)
         if (!ctx[i] || (!out[i] && cap[i])) return RSB_EINVAL;
     int first = RSB_OK;
+    if (one_chain_possible(ctx, nch)) {
+        int rc = run_one_chain(ctx, nch);
+        if (rc != RSB_OK) {
+            // (nothing was collected: every channel's batch is prepared again from scratch by whoever collects it)
+            for (size_t i = 0; i < nch; ++i) {
+                rsb_slot &b = ctx[i]->collect_slot();
+                (void)hipStreamSynchronize(ctx[0]->replay_stream);
+                b.chain_enqueued = false;
+                b.pruned = false;
+                b.time_from = nullptr;
+                ctx[i]->filter_dirty = true;
+                ctx[i]->tables_valid = false;
+            }
+            return rc;
+        }
+        hipStream_t s = ctx[0]->replay_stream;
+        bool tail_on_shared_stream = false;
+        for (size_t i = 0; i < nch; ++i) {
+            n_out[i] = 0;
+            rsb_ctx *c = ctx[i];
+            c->chain_stream = s;
+            rc = rsb_collect_begin(c, out[i], cap[i], &n_out[i]);
+            c->chain_stream = nullptr;
+            // a channel that went on iterating (or fell back to the host path) has left work for its tables on the shared stream
+            if (c->timing.replay_iterations != 1 || !c->timing.replay_on_device) tail_on_shared_stream = true;
+            if (rc != RSB_OK && first == RSB_OK) first = rc;
+        }
+        // ... which that channel's own stream knows nothing of: wait for it here (rare)
+        if (tail_on_shared_stream && hipStreamSynchronize(s) != hipSuccess && first == RSB_OK) first = RSB_ENODEV;
+        for (size_t i = 0; i < nch; ++i) {
+            rc = rsb_collect_wait(ctx[i]);
+            if (rc != RSB_OK && first == RSB_OK) first = rc;
+        }
+        return first;
+    }
     // every channel's prune / replay / emit chain onto its own stream first: they run side by side ...
     for (size_t i = 0; i < nch; ++i) {
         const int rc = rsb_collect_prepare(ctx[i]);

@@ -36,8 +36,11 @@ struct rsb_slot {
     uint32_t *h_pin = nullptr;        // pinned: what the host reads back per batch (changed flag, counters, block counts, first new adders)
     bool chain_enqueued = false;      // the first replay round, the records and the readbacks are on the replay stream already
     bool chain_count_on_device = false, chain_to_host = false;
+    bool chain_folded = false;        // rsb_collect_many's shared chain folded the batch's new members into the tables already
+    const rsb_slot *time_from = nullptr;  // ... and its stage times are in that slot's events
     rsb::ReplayArgs chain_r;
     bool pending = false;
+    uint64_t submit_seq = 0;  // the order in which the batches of all contexts were submitted
     float scan_share = 1.0f;  // rsb_submit_many: this channel's share of the one scan launch (timing.scan_ms)
     const double *means_on_device = nullptr;  // per-block (mean_level, mean_power) of the pending batch, when taken from float means
     uint64_t pending_n = 0, g0 = 0;   // samples of the batch, its stream position
@@ -176,6 +179,10 @@ struct rsb_ctx {
     hipEvent_t many_args_read[2] = {nullptr, nullptr};
     bool many_args_pending[2] = {false, false};
     unsigned many_calls = 0;
+    hipStream_t chain_stream = nullptr;     // set while rsb_collect_many collects this channel behind a chain shared with other channels
+    rsb::ChainArgs *d_chain_args = nullptr, *h_chain_args = nullptr;  // rsb_collect_many: the channels' chain arguments (held by the first channel)
+    uint32_t *d_chain_back = nullptr, *h_chain_back = nullptr;        // ... and what comes back of every channel, gathered
+    size_t chain_args_cap = 0, chain_back_cap = 0;
     size_t merge_cap = 0;
 
     // grid_limit: the scan workgroups this batch may have (0 = the context's scan_grid; rsb_submit_many gives every channel its share)

@@ -1409,7 +1409,7 @@ __global__ __launch_bounds__(kThreads) void k_prune(const BatchArgs a) {
 // -- the members and a few per cent of the others -- go to the bitmap.
 __device__ __forceinline__ uint32_t summary_bit(uint32_t v) { return (v ^ (v >> 9)) & (32u * kSummaryWords - 1u); }
 
-__global__ __launch_bounds__(kThreads) void k_prune_summary(const uint32_t *bitmap, uint32_t *summary) {
+__device__ __forceinline__ void prune_summary_body(const uint32_t *bitmap, uint32_t *summary) {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;  // one 16-byte piece of the bitmap per thread
     const uint4 w = ((const uint4 *)bitmap)[i];
     const uint32_t W[4] = {w.x, w.y, w.z, w.w};
@@ -1433,7 +1433,8 @@ __device__ __forceinline__ bool prune_keeps(const BatchArgs &a, const ItemRec &r
 // kept items (6 % on the benchmark's traffic: 13 M items per Gsample are decided, 0.8 M move).
 constexpr int kPruneUnroll = 4;
 
-__global__ __launch_bounds__(kThreads) void k_prune_count(const BatchArgs a) {
+__device__ __forceinline__ void prune_count_body(const BatchArgs &a) {
+    if (blockIdx.x >= a.n_regions) return;  // (a launch for several batches: the grid is the largest batch's)
     __shared__ uint32_t wave_kept[kThreads / 64];
     __shared__ __attribute__((aligned(16))) uint32_t summary[kSummaryWords];
     static_assert(kSummaryWords == 4 * kThreads, "one 16-byte piece per thread");
@@ -1499,7 +1500,8 @@ __device__ __forceinline__ uint64_t chunk_word_bits(uint32_t first, uint32_t n, 
     return bits;
 }
 
-__global__ __launch_bounds__(kChunkGroup) void k_prune_chunks(const BatchArgs a) {
+__device__ __forceinline__ void prune_chunks_body(const BatchArgs &a) {
+    if (blockIdx.x * kChunkGroup >= a.n_chunks) return;
     __shared__ uint32_t wave_sum[kChunkGroup / 64], wave_all[kChunkGroup / 64];
     const uint32_t c = blockIdx.x * kChunkGroup + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t kept = 0, all = 0;
@@ -1535,7 +1537,7 @@ __global__ __launch_bounds__(kChunkGroup) void k_prune_chunks(const BatchArgs a)
 }
 
 // exclusive sum over the groups' totals (one workgroup; a Gsample has a few hundred groups); the total goes to the counters
-__global__ __launch_bounds__(1024) void k_prune_offsets(const BatchArgs a) {
+__device__ __forceinline__ void prune_offsets_body(const BatchArgs &a) {
     __shared__ uint32_t part[1024];
     const uint32_t ngroups = (a.n_chunks + kChunkGroup - 1) / kChunkGroup;
     const uint32_t t = threadIdx.x, per = (ngroups + 1023) / 1024, lo = min(ngroups, t * per), hi = min(ngroups, lo + per);
@@ -1561,7 +1563,7 @@ __global__ __launch_bounds__(1024) void k_prune_offsets(const BatchArgs a) {
 // Eight lanes per chunk: its kept items to their places.  Sub-lane l takes keep mask word l of the chunk (a chunk of two strips has
 // two or three), so the words and then the kept items of eight chunks are fetched side by side in a wavefront.
 constexpr int kWriteLanes = 8;
-__global__ __launch_bounds__(kThreads) void k_prune_write(const BatchArgs a) {
+__device__ __forceinline__ void prune_write_body(const BatchArgs &a) {
     const uint32_t sub = threadIdx.x & (kWriteLanes - 1), c = (blockIdx.x * kThreads + threadIdx.x) / kWriteLanes;
     const bool live = c < a.n_chunks;
     const uint2 d = live ? a.chunk_dir[c] : make_uint2(0, 0);
@@ -1677,7 +1679,7 @@ __device__ __forceinline__ uint32_t items_of(const ReplayArgs &r) { return r.n_d
 
 // first item of every 131072-sample block in the sorted item list (blk_start[nblocks] = n_items); also clears the counters the
 // replay's later kernels add to
-__global__ __launch_bounds__(kThreads) void k_replay_bounds(const ReplayArgs r) {
+__device__ __forceinline__ void replay_bounds_body(const ReplayArgs &r) {
     const uint32_t n_items = items_of(r);
     if (blockIdx.x == 0 && threadIdx.x < 6 && r.counters) {
         static_assert(kCntNewAdders == kCntAccepted + 1 && kCntAccE0 == kCntAccepted + 2 && kCntAccE2 == kCntAccepted + 4, "one run of counters");
@@ -1695,7 +1697,7 @@ __global__ __launch_bounds__(kThreads) void k_replay_bounds(const ReplayArgs r) 
 // that offset's best phase by strict '>' (demod_2400.c:290-301; at most five items, one per trial phase) and asks whether
 // decodeModesMessage would take it.  cand[i] = 0, or for such an offset: (best score + 1) | best item's distance << 16 |
 // (112-bit frame) << 20.  Fully parallel: the sequential part is left to k_replay_walk.
-__global__ __launch_bounds__(kThreads) void k_replay_score(const ReplayArgs r) {
+__device__ __forceinline__ void replay_score_body(const ReplayArgs &r) {
     const uint32_t n_items = items_of(r);
     if (blockIdx.x == 0 && threadIdx.x == 0 && r.counters) r.counters[kCntChanged] = 0;  // (k_replay_compare of this round raises it)
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_items; i += gridDim.x * kThreads) {
@@ -1730,7 +1732,7 @@ __global__ __launch_bounds__(kThreads) void k_replay_score(const ReplayArgs r) {
 
 // One wavefront per 131072-sample block (one demodulate2400 call): the offsets that could be accepted, 64 items at a
 // time, are chained in ascending order through the greedy skip (demod_2400.c:371) -- the only sequential part.
-__global__ __launch_bounds__(kThreads) void k_replay_walk(const ReplayArgs r) {
+__device__ __forceinline__ void replay_walk_body(const ReplayArgs &r) {
     __shared__ uint32_t cand_g[kThreads / 64][64];
     __shared__ uint32_t cand_len[kThreads / 64][64];
     __shared__ uint32_t cand_ok[kThreads / 64][64];   // 0, or 1 + the message's rank among the block's accepted messages
@@ -1778,7 +1780,7 @@ __global__ __launch_bounds__(kThreads) void k_replay_walk(const ReplayArgs r) {
 }
 
 // accepted messages before every 131072-sample block (blk_base[nblocks] = all of the batch's, also to counters[kCntAccepted])
-__global__ __launch_bounds__(1024) void k_replay_blkbase(const ReplayArgs r) {
+__device__ __forceinline__ void replay_blkbase_body(const ReplayArgs &r) {
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x, per = (r.nblocks + 1023) / 1024, lo = min(r.nblocks, t * per), hi = min(r.nblocks, lo + per);
     uint32_t sum = 0;
@@ -1813,7 +1815,7 @@ __global__ __launch_bounds__(1024) void k_replay_blkbase(const ReplayArgs r) {
 //   else: the items the walk accepted, into the next table.
 constexpr int kMinSlots = 2048, kMinItemsPerGroup = 8192;
 template <bool SEED>
-__global__ __launch_bounds__(kThreads) void k_replay_table_min(const ReplayArgs r) {
+__device__ __forceinline__ void replay_table_min_body(const ReplayArgs &r) {
     __shared__ uint32_t key[kMinSlots], val[kMinSlots];
     uint32_t *table = SEED ? r.t_cur : r.t_next;
     for (uint32_t i = threadIdx.x; i < (uint32_t)kMinSlots; i += kThreads) {
@@ -1853,7 +1855,7 @@ __global__ __launch_bounds__(kThreads) void k_replay_table_min(const ReplayArgs 
 }
 
 // over the items that can add an address: did the table move / reset / list / fold
-__global__ __launch_bounds__(kThreads) void k_replay_compare(const ReplayArgs r, uint32_t *changed) {
+__device__ __forceinline__ void replay_compare_body(const ReplayArgs &r, uint32_t *changed) {
     const uint32_t n_items = items_of(r);
     bool any = false;
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_items; i += gridDim.x * kThreads) {
@@ -1873,7 +1875,7 @@ __global__ __launch_bounds__(kThreads) void k_replay_reset(const ReplayArgs r, u
         if (table[v] != 0) table[v] = kNever;  // 0 = known before this batch: stays
     }
 }
-__global__ __launch_bounds__(kThreads) void k_replay_list(const ReplayArgs r, uint32_t *counters) {
+__device__ __forceinline__ void replay_list_body(const ReplayArgs &r, uint32_t *counters) {
     const uint32_t n_items = items_of(r);
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_items; i += gridDim.x * kThreads) {
         if (r.acc[i] == 0) continue;
@@ -1889,7 +1891,7 @@ __global__ __launch_bounds__(kThreads) void k_replay_list(const ReplayArgs r, ui
         }
     }
 }
-__global__ __launch_bounds__(kThreads) void k_replay_fold(const ReplayArgs r) {
+__device__ __forceinline__ void replay_fold_body(const ReplayArgs &r) {
     const uint32_t n_items = items_of(r);
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_items; i += gridDim.x * kThreads) {
         const uint32_t info = r.info[i];
@@ -1942,7 +1944,7 @@ struct __attribute__((aligned(16))) EmitShared {
 typedef uint4 __attribute__((aligned(4))) uint4_a4;
 
 template <int FMT>
-__global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs a, const ReplayArgs r) {
+__device__ __forceinline__ void replay_emit_body(const BatchArgs &a, const ReplayArgs &r) {
     extern __shared__ __attribute__((aligned(16))) unsigned char emit_lds[];  // 66 KB: over the static limit
     EmitShared &sh = *reinterpret_cast<EmitShared *>(emit_lds);
     constexpr uint32_t kT = 64 * kEmitWaves;
@@ -2216,6 +2218,119 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs
         atomicAdd(&a.counters[kDbgEmitIters], eiters);
     }
 #endif
+}
+
+// ---- the kernels of the prune / replay chain: one batch per launch (arguments by value), or -- the *_many forms -- the batches of
+// several channels in one launch: blockIdx.y picks the channel, whose arguments arrive by scalar loads from a device array, and the
+// grid's x extent is the largest channel's (every body strides or checks its own batch's sizes).  Thirty-two channels' chains are
+// then 16 launches instead of 500, and their small kernels fill the chip together.
+__device__ __forceinline__ bool chain_idle(const ChainArgs &c) { return c.a.n == 0 || c.r.nblocks == 0; }
+
+__global__ __launch_bounds__(kThreads) void k_prune_summary(const uint32_t *bitmap, uint32_t *summary) { prune_summary_body(bitmap, summary); }
+__global__ __launch_bounds__(kThreads) void k_prune_count(const BatchArgs a) { prune_count_body(a); }
+__global__ __launch_bounds__(kChunkGroup) void k_prune_chunks(const BatchArgs a) { prune_chunks_body(a); }
+__global__ __launch_bounds__(1024) void k_prune_offsets(const BatchArgs a) { prune_offsets_body(a); }
+__global__ __launch_bounds__(kThreads) void k_prune_write(const BatchArgs a) { prune_write_body(a); }
+__global__ __launch_bounds__(kThreads) void k_replay_bounds(const ReplayArgs r) { replay_bounds_body(r); }
+__global__ __launch_bounds__(kThreads) void k_replay_score(const ReplayArgs r) { replay_score_body(r); }
+__global__ __launch_bounds__(kThreads) void k_replay_walk(const ReplayArgs r) { replay_walk_body(r); }
+__global__ __launch_bounds__(1024) void k_replay_blkbase(const ReplayArgs r) { replay_blkbase_body(r); }
+template <bool SEED>
+__global__ __launch_bounds__(kThreads) void k_replay_table_min(const ReplayArgs r) { replay_table_min_body<SEED>(r); }
+__global__ __launch_bounds__(kThreads) void k_replay_compare(const ReplayArgs r, uint32_t *changed) { replay_compare_body(r, changed); }
+__global__ __launch_bounds__(kThreads) void k_replay_list(const ReplayArgs r, uint32_t *counters) { replay_list_body(r, counters); }
+__global__ __launch_bounds__(kThreads) void k_replay_fold(const ReplayArgs r) { replay_fold_body(r); }
+template <int FMT>
+__global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs a, const ReplayArgs r) { replay_emit_body<FMT>(a, r); }
+
+// (the summary words start at zero: this kernel stands where launch_prune_ordered has its memset)
+__global__ __launch_bounds__(kThreads) void k_prune_summary_clear_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (chain_idle(c) || !c.a.adder_summary) return;
+    static_assert(kSummaryWords == 4 * kThreads, "one 16-byte piece per thread");
+    ((uint4 *)c.a.adder_summary)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+}
+__global__ __launch_bounds__(kThreads) void k_prune_summary_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (chain_idle(c) || !c.a.adder_summary) return;
+    prune_summary_body(c.a.adder_bitmap, c.a.adder_summary);
+}
+__global__ __launch_bounds__(kThreads) void k_prune_count_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) prune_count_body(c.a);
+}
+__global__ __launch_bounds__(kChunkGroup) void k_prune_chunks_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) prune_chunks_body(c.a);
+}
+__global__ __launch_bounds__(1024) void k_prune_offsets_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) prune_offsets_body(c.a);
+}
+__global__ __launch_bounds__(kThreads) void k_prune_write_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) prune_write_body(c.a);
+}
+__global__ __launch_bounds__(kThreads) void k_replay_bounds_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) replay_bounds_body(c.r);
+}
+template <bool SEED>
+__global__ __launch_bounds__(kThreads) void k_replay_table_min_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) replay_table_min_body<SEED>(c.r);
+}
+__global__ __launch_bounds__(kThreads) void k_replay_score_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) replay_score_body(c.r);
+}
+__global__ __launch_bounds__(kThreads) void k_replay_walk_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) replay_walk_body(c.r);
+}
+__global__ __launch_bounds__(kThreads) void k_replay_compare_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) replay_compare_body(c.r, &c.r.counters[kCntChanged]);
+}
+__global__ __launch_bounds__(1024) void k_replay_blkbase_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (chain_idle(c)) return;
+    if (threadIdx.x < 4) c.r.counters[kCntNewAdders + threadIdx.x] = 0;  // (launch_replay_select's memset: new adders, accepted by errors)
+    replay_blkbase_body(c.r);
+}
+__global__ __launch_bounds__(kThreads) void k_replay_list_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) replay_list_body(c.r, c.r.counters);
+}
+template <int FMT>
+__global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) replay_emit_body<FMT>(c.a, c.r);
+}
+// A channel whose first round was the fixed point (nearly every one) folds its new members into the tables here and now; the
+// others are iterated on by the host, channel by channel, which folds when it is through.  Then what the host wants to see of every
+// channel, gathered into one block that crosses PCIe in one copy:
+//   [changed | counters (kCntCount) | accepted messages per block (max_nblocks) | the first kPinAdders new adders]
+__global__ __launch_bounds__(kThreads) void k_replay_fold_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (chain_idle(c) || c.r.counters[kCntChanged] != 0) return;
+    replay_fold_body(c.r);
+}
+__global__ __launch_bounds__(kThreads) void k_chain_readback_many(const ChainArgs *__restrict__ m, uint32_t *__restrict__ out, uint32_t stride, uint32_t max_nblocks,
+                                                                  uint32_t pin_adders) {
+    const ChainArgs &c = m[blockIdx.y];
+    uint32_t *o = out + (size_t)blockIdx.y * stride;
+    if (chain_idle(c)) {
+        for (uint32_t i = threadIdx.x; i < 1 + (uint32_t)kCntCount; i += kThreads) o[i] = 0;
+        return;
+    }
+    const uint32_t *cnt = c.r.counters;
+    if (threadIdx.x == 0) o[0] = cnt[kCntChanged];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kCntCount; i += kThreads) o[1 + i] = cnt[i];
+    for (uint32_t i = threadIdx.x; i < c.r.nblocks; i += kThreads) o[1 + kCntCount + i] = c.r.blk_counts[i];
+    const uint32_t nadd = min(min(cnt[kCntNewAdders], c.r.new_adders_cap), pin_adders);
+    const uint32_t *src = (const uint32_t *)c.r.new_adders;
+    for (uint32_t i = threadIdx.x; i < 2 * nadd; i += kThreads) o[1 + kCntCount + max_nblocks + i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3192,9 +3307,16 @@ inline unsigned run_grid(uint32_t n) {  // k_replay_table_min: one workgroup per
 }
 }  // namespace
 
+// RSB_PESSIMISTIC_START=1 (tests): the fixed-point iteration starts from the filter as it was before the batch instead of from the
+// optimistic seed, so every batch that teaches the filter an address goes through the correction rounds
+static bool pessimistic_start() {
+    const char *e = std::getenv("RSB_PESSIMISTIC_START");
+    return e && std::atoi(e) != 0;
+}
+
 hipError_t launch_replay_bounds(const ReplayArgs &r, hipStream_t s) {
     hipLaunchKernelGGL(k_replay_bounds, dim3(item_grid(r.n_items + 1)), dim3(kThreads), 0, s, r);
-    if (r.n_items && r.t_cur) hipLaunchKernelGGL(k_replay_table_min<true>, dim3(run_grid(r.n_items)), dim3(kThreads), 0, s, r);
+    if (r.n_items && r.t_cur && !pessimistic_start()) hipLaunchKernelGGL(k_replay_table_min<true>, dim3(run_grid(r.n_items)), dim3(kThreads), 0, s, r);
     return hipGetLastError();
 }
 
@@ -3236,6 +3358,50 @@ hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream
         hipLaunchKernelGGL(kern, dim3(g < 1 ? 1 : (g > (unsigned)kEmitGroups ? (unsigned)kEmitGroups : g)), dim3(64 * kEmitWaves), sizeof(EmitShared), s, a, r);
         return hipGetLastError();
     });
+}
+
+// One launch per stage for all the channels' batches (args_dev[i] = channel i's {BatchArgs, ReplayArgs}; d gives the grids' extents).
+hipError_t launch_chain_prune_many(const ChainArgs *args_dev, const ChainDims &d, hipStream_t s) {
+    if (d.nch == 0) return hipSuccess;
+    if (d.any_summary) {
+        hipLaunchKernelGGL(k_prune_summary_clear_many, dim3(1, d.nch), dim3(kThreads), 0, s, args_dev);
+        hipLaunchKernelGGL(k_prune_summary_many, dim3((1u << 24) / 32 / 4 / kThreads, d.nch), dim3(kThreads), 0, s, args_dev);
+    }
+    const unsigned chunks = d.max_chunks ? d.max_chunks : 1u;
+    hipLaunchKernelGGL(k_prune_count_many, dim3(d.max_regions ? d.max_regions : 1u, d.nch), dim3(kThreads), 0, s, args_dev);
+    hipLaunchKernelGGL(k_prune_chunks_many, dim3((chunks + kChunkGroup - 1) / kChunkGroup, d.nch), dim3(kChunkGroup), 0, s, args_dev);
+    hipLaunchKernelGGL(k_prune_offsets_many, dim3(1, d.nch), dim3(1024), 0, s, args_dev);
+    hipLaunchKernelGGL(k_prune_write_many, dim3((chunks + kThreads / kWriteLanes - 1) / (kThreads / kWriteLanes), d.nch), dim3(kThreads), 0, s, args_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain_replay_many(int fmt, const ChainArgs *args_dev, const ChainDims &d, uint32_t *readback_dev, uint32_t readback_stride, uint32_t pin_adders,
+                                    hipStream_t s) {
+    if (d.nch == 0) return hipSuccess;
+    const unsigned items = item_grid(d.max_items), items1 = item_grid(d.max_items + 1), runs = run_grid(d.max_items);
+    hipLaunchKernelGGL(k_replay_bounds_many, dim3(items1, d.nch), dim3(kThreads), 0, s, args_dev);
+    if (!pessimistic_start()) hipLaunchKernelGGL(k_replay_table_min_many<true>, dim3(runs, d.nch), dim3(kThreads), 0, s, args_dev);
+    hipLaunchKernelGGL(k_replay_score_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
+    hipLaunchKernelGGL(k_replay_walk_many, dim3((d.max_nblocks + kThreads / 64 - 1) / (kThreads / 64), d.nch), dim3(kThreads), 0, s, args_dev);
+    hipLaunchKernelGGL(k_replay_table_min_many<false>, dim3(runs, d.nch), dim3(kThreads), 0, s, args_dev);
+    hipLaunchKernelGGL(k_replay_compare_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
+    hipLaunchKernelGGL(k_replay_blkbase_many, dim3(1, d.nch), dim3(1024), 0, s, args_dev);
+    hipLaunchKernelGGL(k_replay_list_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
+    hipError_t e = by_format(fmt, [&](auto F) {
+        auto kern = k_replay_emit_many<decltype(F)::value>;
+        const hipError_t e2 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmitShared));
+        if (e2 != hipSuccess) return e2;
+        // every workgroup pays the table set-up (33 us): the chip's worth of workgroups shared out over the channels
+        unsigned g = (d.max_items / 4 + 64 * kEmitWaves - 1) / (64 * kEmitWaves), share = (unsigned)kEmitGroups / d.nch;
+        if (share < 1) share = 1;
+        if (g > share) g = share;
+        hipLaunchKernelGGL(kern, dim3(g < 1 ? 1 : g, d.nch), dim3(64 * kEmitWaves), sizeof(EmitShared), s, args_dev);
+        return hipGetLastError();
+    });
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_replay_fold_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
+    hipLaunchKernelGGL(k_chain_readback_many, dim3(1, d.nch), dim3(kThreads), 0, s, args_dev, readback_dev, readback_stride, d.max_nblocks, pin_adders);
+    return hipGetLastError();
 }
 
 hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s) {

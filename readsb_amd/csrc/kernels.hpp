@@ -147,6 +147,19 @@ struct ReplayArgs {
 };
 constexpr uint32_t kNever = 0xffffffffu;
 
+// One channel's batch in a launch that takes the batches of several channels (rsb_collect_many)
+struct ChainArgs {
+    BatchArgs a;
+    ReplayArgs r;
+};
+struct ChainDims {
+    uint32_t nch;          // channels (the grids' y extent)
+    uint32_t max_regions, max_chunks;   // the largest BatchArgs::n_regions / n_chunks
+    uint32_t max_items;    // the largest bound on the kept items (ReplayArgs::n_items)
+    uint32_t max_nblocks;  // the largest ReplayArgs::nblocks
+    bool any_summary;      // some channel's prune uses the hashed summary of the bitmap
+};
+
 int scan_grid_size(int device);
 hipError_t launch_scan(const BatchArgs &a, int grid, hipStream_t s);
 // nbatches batches of one format in one launch: args_dev[i] built for groups_per_batch workgroups (n_regions = 16 x that), n = 0 allowed
@@ -170,6 +183,12 @@ hipError_t launch_replay_select(const BatchArgs &a, const ReplayArgs &r, void *t
 hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream_t s);
 // (launch_replay_select leaves the tables alone; this folds the batch's new members into them once the fixed point is certain)
 hipError_t launch_replay_fold(const ReplayArgs &r, hipStream_t s);
+// The whole chain for several channels' batches, one launch per stage (kernels.hip "the *_many forms"): the ordered prune, then
+// bounds / seed / score / walk / adds / compare / places / list / records / fold-if-converged, then every channel's
+// [changed | counters | block counts | first pin_adders new adders] gathered to readback_dev + i * readback_stride (words).
+hipError_t launch_chain_prune_many(const ChainArgs *args_dev, const ChainDims &d, hipStream_t s);
+hipError_t launch_chain_replay_many(int fmt, const ChainArgs *args_dev, const ChainDims &d, uint32_t *readback_dev, uint32_t readback_stride, uint32_t pin_adders,
+                                    hipStream_t s);
 // wire formats (wire.hpp) of n message records on the device: launch_wire_offsets leaves the byte offset of message i in
 // off[i] and the total in off[n]; launch_wire_write stores the bytes at out + off[i]
 struct WireArgs {

@@ -852,6 +852,56 @@ def test_one_scan_launch_for_many_channels(fmt, modeac, built):
         c.close()
 
 
+@pytest.mark.parametrize("pessimistic", [False, True])
+def test_thirty_two_channels_share_one_chain(pessimistic, built, monkeypatch):
+    """rsb_collect_many runs the prune / replay / emit chains of all channels as ONE chain of launches (blockIdx.y = channel) with one
+    host wait.  Thirty-two channels of different lengths (empty, shorter than a strip, ragged, several blocks), half of them with
+    Mode A/C, two rounds, an address added from outside to two channels between the rounds (their tables are mirrored inside the shared
+    chain) -- every channel's list against the oracle.  With RSB_PESSIMISTIC_START=1 no channel's first round is the fixed point: each
+    goes on iterating by itself behind the shared chain.  That the shared chain ran is seen from the stage times (one set of events
+    for all channels); RSB_NO_CHAIN_MANY=1 gives the same lists from per-channel chains."""
+    import torch
+    from readsb_amd.synth import Scenario
+
+    if pessimistic:
+        monkeypatch.setenv("RSB_PESSIMISTIC_START", "1")
+    B, nch = 131072, 32
+    lens = [3 * B, 2 * B, 1000, 0, B, 4 * B, 2 * B, 700_000]
+    first = [lens[k % 8] for k in range(nch)]
+    second = [None if first[k] % B or first[k] == 0 else (B + 77 * k if k % 3 else 2 * B) for k in range(nch)]
+    iqs = [generate(Scenario(first[k] + (second[k] or 0), seed=900 + k, frames_per_sec=2000 + 150 * k, modeac_per_sec=300 if k & 1 else 0,
+                             collide_every=5 if k % 4 == 0 else 0)) if first[k] else np.zeros((0, 2), dtype=np.uint8) for k in range(nch)]
+    devs = [torch.from_numpy(np.ascontiguousarray(x)).cuda() if x.shape[0] else torch.zeros(16, dtype=torch.uint8, device="cuda") for x in iqs]
+    want = [Oracle(fmt="UC8", nfix=1, modeac=bool(k & 1)).run_stream(iqs[k])[0] if first[k] else np.zeros(0, dtype=REC_DTYPE) for k in range(nch)]
+    live = [k for k in range(nch) if second[k] is not None]
+    lists = {}
+    for shared in (True, False):
+        if not shared:
+            monkeypatch.setenv("RSB_NO_CHAIN_MANY", "1")
+        chans = [readsb_amd.Channel(fmt="UC8", fix_bits=1, mode_ac=bool(k & 1), max_batch_samples=6 * B) for k in range(nch)]
+        outs = [torch.empty((1 << 14) * 56, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE) for _ in range(nch)]
+        got = [[] for _ in range(nch)]
+        readsb_amd.submit_many(chans, [d.data_ptr() for d in devs], first)
+        for k, part in enumerate(readsb_amd.collect_many(chans, outs)):
+            got[k].append(part.copy())
+        times = {chans[k].timing()["device_replay_ms"] for k in range(nch) if first[k]}
+        assert (len(times) == 1) == shared and min(times) > 0, times
+        iters = [chans[k].timing()["replay_iterations"] for k in range(nch) if first[k] >= B]
+        assert (min(iters) >= 2) if pessimistic else (max(iters) <= 2), iters
+        for k in (live[0], live[5]):
+            chans[k].filter_add(0xABCDEF)  # matches nothing in these recordings
+        readsb_amd.submit_many([chans[k] for k in live], [devs[k].data_ptr() + 2 * first[k] for k in live], [second[k] for k in live])
+        for k, part in zip(live, readsb_amd.collect_many([chans[k] for k in live], [outs[k] for k in live])):
+            got[k].append(part.copy())
+        lists[shared] = [np.concatenate(g) for g in got]
+        for c in chans:
+            c.close()
+    for k in range(nch):
+        assert first_mismatch(want[k], lists[True][k].view(REC_DTYPE)) is None, k
+        assert lists[True][k].tobytes() == lists[False][k].tobytes(), k
+    assert sum(w.size for w in want) > 8000
+
+
 def Scenario_for(k):
     from readsb_amd.synth import Scenario
 
