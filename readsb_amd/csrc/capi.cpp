@@ -125,6 +125,7 @@ int setup_device(rsb_ctx *c) {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->replay_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->reset_done, hipEventDisableTiming));
     for (void *&p : c->d_carry) HIP_TRY(c, hipMalloc(&p, kTrailing * 4));
     c->sort_temp_bytes = sort_temp_bytes(c->surv_item_cap);
     HIP_TRY(c, hipMalloc(&c->d_sort_temp, c->sort_temp_bytes));
@@ -164,10 +165,14 @@ int setup_device(rsb_ctx *c) {
 
 int reset_device(rsb_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    HIP_TRY(c, hipMemset(c->d_bitmap, 0, (1u << 24) / 8));
+    // On the context's own stream, without a host wait (a blocking memset and copy were 45 us per reset: 1.4 ms for 32 channels):
+    // whatever reads or writes the bitmap next is either on that stream (prune, rsb_superset_add, rsb_export_adders) or waits for
+    // reset_done first (the next scan: enqueue_before_scan; fetch_bitmap).
+    HIP_TRY(c, hipMemsetAsync(c->d_bitmap, 0, (1u << 24) / 8, c->replay_stream));
     // icaoFilterTest(0) is true on an empty slot (icao_filter.c:101-107): address 0 is always a "member"
-    const uint32_t one = 1;
-    HIP_TRY(c, hipMemcpy(c->d_bitmap, &one, sizeof(one), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_bitmap, 1, 1, c->replay_stream));
+    HIP_TRY(c, hipEventRecord(c->reset_done, c->replay_stream));
+    c->reset_pending = true;
     c->filter_dirty = true;
     return RSB_OK;
 }
@@ -551,11 +556,14 @@ void rsb_destroy(rsb_ctx *c) {
     if (c->h_chain_args) (void)hipHostFree(c->h_chain_args);
     if (c->d_chain_args) (void)hipFree(c->d_chain_args);
     if (c->h_chain_back) (void)hipHostFree(c->h_chain_back);
+    if (c->h_mirror) (void)hipHostFree(c->h_mirror);
+    if (c->d_mirror) (void)hipFree(c->d_mirror);
     if (c->d_chain_back) (void)hipFree(c->d_chain_back);
     for (hipEvent_t ev : c->many_args_read)
         if (ev) (void)hipEventDestroy(ev);
     if (c->addr_upload_done) (void)hipEventDestroy(c->addr_upload_done);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    if (c->reset_done) (void)hipEventDestroy(c->reset_done);
     void *ptrs[] = {c->d_lut, c->d_radial, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
                     c->d_bitmap, c->d_summary, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
                     c->d_magbuf, c->d_sub_means, c->d_wave_times, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge, c->d_dec_in, c->d_decoded, c->d_addr_list};
@@ -635,6 +643,7 @@ static int fetch_bitmap(rsb_ctx *c, std::vector<uint32_t> &words) {
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     for (rsb_slot &b : c->slots)
         if (b.pending) HIP_TRY(c, hipEventSynchronize(b.ev[3]));
+    if (c->reset_pending) HIP_TRY(c, hipEventSynchronize(c->reset_done));
     words.resize((1u << 24) / 32);
     HIP_TRY(c, hipMemcpy(words.data(), c->d_bitmap, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return RSB_OK;
@@ -752,17 +761,24 @@ int rsb_filter_export(rsb_ctx *c, uint32_t *out, size_t cap, size_t *n_out) {
 // part of all its channels
 static std::atomic<uint64_t> g_submit_seq{0};  // orders the ev[3] records of all contexts (rsb_collect_many: which of one stream's is the last)
 
-static int enqueue_before_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, hipStream_t s, bool record_start = true) {
+// in_one_launch: the batch is one of rsb_submit_many's single scan launch, whose prepare kernel zeroes the counters of all its batches
+static int enqueue_before_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, hipStream_t s, bool in_one_launch = false) {
     // (one-slot contexts: a record copy still in flight may read this slot's item buffer -- a list merged with Mode A/C messages)
     if (c->copy_in_flight && c->copy_slot == &b) HIP_TRY(c, hipStreamWaitEvent(s, c->copy_done, 0));
+    if (c->reset_pending) {  // rsb_reset cleared the prune's superset on the context's own stream
+        HIP_TRY(c, hipStreamWaitEvent(s, c->reset_done, 0));
+        c->reset_pending = false;
+    }
+    b.scan_share = 1.0f;
+    b.scan_timed = b.ac_timed = true;
+    if (in_one_launch) return RSB_OK;
     HIP_TRY(c, hipMemsetAsync(b.d_counters, 0, kCntAlloc * sizeof(uint32_t), s));
     HIP_TRY(c, hipMemsetAsync(b.d_region_counts, 0, (size_t)a.n_regions * sizeof(uint32_t), s));
-    b.scan_share = 1.0f;
-    if (record_start) HIP_TRY(c, hipEventRecord(b.ev[0], s));
+    HIP_TRY(c, hipEventRecord(b.ev[0], s));
     return RSB_OK;
 }
 
-static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s, bool record_scan_end = true);
+static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s, bool in_one_launch = false);
 
 static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
     int rc = enqueue_before_scan(c, b, a, s);
@@ -771,16 +787,19 @@ static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t n
     return enqueue_after_scan(c, b, a, nsamples, s);
 }
 
-static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s, bool record_scan_end) {
-    if (record_scan_end) HIP_TRY(c, hipEventRecord(b.ev[1], s));
+static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s, bool in_one_launch) {
+    if (!in_one_launch) HIP_TRY(c, hipEventRecord(b.ev[1], s));
     // The prune runs at the head of the batch's replay chain, on the context's own stream (rsb_collect, or collect_ahead while
     // the batch before is being delivered), not here: the caller's stream then carries the scans of successive batches back to
     // back, and the prune sees whatever the caller has added to the superset in between (RSB_FLAG_DEFER_PRUNE relies on that).
     b.pruned = false;
     b.pruned_in_order = false;
-    HIP_TRY(c, hipEventRecord(b.ev[2], s));
+    const bool ac_work = (c->run_ac || c->exact_stats) && nsamples;
+    // (the one launch for many channels: no event per channel where nothing lies between it and the next one)
+    if (!in_one_launch || ac_work) HIP_TRY(c, hipEventRecord(b.ev[2], s));
+    else b.ac_timed = false;
     b.means_on_device = nullptr;
-    if ((c->run_ac || c->exact_stats) && nsamples) {
+    if (ac_work) {
         // mag_buf.mean_level / mean_power of every block: demodulate2400AC's noise level (demod_2400.c:484-485) and the
         // noise power statistic (:378-382)
         const size_t nblk = (nsamples + c->block_len - 1) / c->block_len;
@@ -808,7 +827,8 @@ static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint6
         // the next batch's 326-sample overlap (sdr_ifile.c:199-201)
         const unsigned bps = (a.fmt == kFmtUC8 || a.fmt == kFmtMag16) ? 2 : 4;
         const unsigned k = (c->submitted + 1) % rsb_ctx::kCarries;
-        HIP_TRY(c, hipMemcpyAsync(c->d_carry[k], (const char *)a.iq + (nsamples - kTrailing) * bps, (size_t)kTrailing * bps, hipMemcpyDeviceToDevice, s));
+        if (!a.carry_out)  // (else the one launch's prepare kernel has copied it)
+            HIP_TRY(c, hipMemcpyAsync(c->d_carry[k], (const char *)a.iq + (nsamples - kTrailing) * bps, (size_t)kTrailing * bps, hipMemcpyDeviceToDevice, s));
         c->carry_valid[k] = 1;
     }
     HIP_TRY(c, hipEventRecord(b.ev[3], s));
@@ -1166,11 +1186,14 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     c->timing.copy_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_copy).count();
 
     float ms = 0;
-    (void)hipEventElapsedTime(&c->timing.scan_ms, b.ev[0], b.ev[1]);
-    c->timing.scan_ms *= b.scan_share;
+    c->timing.scan_ms = c->timing.modeac_ms = c->timing.total_ms = 0;
+    if (b.scan_timed) {  // (a channel of rsb_submit_many's one launch other than the first: the launch's time is reported there)
+        (void)hipEventElapsedTime(&c->timing.scan_ms, b.ev[0], b.ev[1]);
+        c->timing.scan_ms *= b.scan_share;
+        (void)hipEventElapsedTime(&c->timing.total_ms, b.ev[0], b.ev[3]);
+    }
     c->timing.prune_ms = 0;
-    (void)hipEventElapsedTime(&c->timing.modeac_ms, b.ev[2], b.ev[3]);
-    (void)hipEventElapsedTime(&c->timing.total_ms, b.ev[0], b.ev[3]);
+    if (b.ac_timed) (void)hipEventElapsedTime(&c->timing.modeac_ms, b.ev[2], b.ev[3]);
     const rsb_slot &tb = b.time_from ? *b.time_from : b;  // (a chain shared by many channels: its times, the same for every channel)
     (void)hipEventElapsedTime(&c->timing.prune_ms, tb.rev[0], tb.rev[1]);  // prune (+ the radix sort in the fallback cases)
     c->timing.sort_ms = 0;
@@ -1436,28 +1459,32 @@ int rsb_submit_many(rsb_ctx *const *ctx, size_t nch, const void *const *iq_dev, 
         if (c0->many_args_pending[half]) HIP_TRY(c0, hipEventSynchronize(c0->many_args_read[half]));
         BatchArgs *h = c0->h_many_args + half * c0->many_args_cap;
         const uint32_t groups = (uint32_t)c0->scan_grid / (uint32_t)nch;  // >= 1: one_scan_launch_possible
+        uint32_t max_regions = 0;
         for (size_t i = 0; i < nch; ++i) {
             rsb_ctx *c = ctx[i];
             h[i] = c->batch_args(c->submit_slot(), iq_dev[i], nsamples[i], c->cfg.input_format, nullptr, (int)groups);
-            const int rc = enqueue_before_scan(c, c->submit_slot(), h[i], s, false);
+            if (nsamples[i] && nsamples[i] % c->block_len == 0) h[i].carry_out = c->d_carry[(c->submitted + 1) % rsb_ctx::kCarries];
+            max_regions = std::max(max_regions, h[i].n_regions);
+            const int rc = enqueue_before_scan(c, c->submit_slot(), h[i], s, true);
             if (rc != RSB_OK) return rc;
         }
         BatchArgs *d_args = c0->d_many_args + half * c0->many_args_cap;
         HIP_TRY(c0, hipMemcpyAsync(d_args, h, nch * sizeof(BatchArgs), hipMemcpyHostToDevice, s));
-        uint64_t total = 0;
-        for (size_t i = 0; i < nch; ++i) total += nsamples[i];
-        for (size_t i = 0; i < nch; ++i) {  // the one launch's time is shared out by samples (rsb_timing.scan_ms)
+        HIP_TRY(c0, launch_submit_prepare_many(d_args, (uint32_t)nch, max_regions, s));
+        // the one launch is timed once, on the first channel's events: rsb_timing.scan_ms is the whole launch there and 0 elsewhere
+        for (size_t i = 0; i < nch; ++i) {
             rsb_slot &b = ctx[i]->submit_slot();
-            b.scan_share = total ? (float)((double)nsamples[i] / (double)total) : 0.0f;
-            HIP_TRY(ctx[i], hipEventRecord(b.ev[0], s));
+            b.scan_share = i == 0 ? 1.0f : 0.0f;
+            b.scan_timed = i == 0;
         }
+        HIP_TRY(c0, hipEventRecord(c0->submit_slot().ev[0], s));
         HIP_TRY(c0, launch_scan_many(c0->cfg.input_format, d_args, (uint32_t)nch, groups, s));
         HIP_TRY(c0, hipEventRecord(c0->many_args_read[half], s));
         c0->many_args_pending[half] = true;
-        for (size_t i = 0; i < nch; ++i) HIP_TRY(ctx[i], hipEventRecord(ctx[i]->submit_slot().ev[1], s));  // the scan's end, before any channel's Mode A/C kernels
+        HIP_TRY(c0, hipEventRecord(c0->submit_slot().ev[1], s));  // the scan's end, before any channel's Mode A/C kernels
         for (size_t i = 0; i < nch; ++i) {
             rsb_ctx *c = ctx[i];
-            const int rc = enqueue_after_scan(c, c->submit_slot(), h[i], nsamples[i], s, false);
+            const int rc = enqueue_after_scan(c, c->submit_slot(), h[i], nsamples[i], s, true);
             if (rc != RSB_OK) return rc;
         }
         return RSB_OK;
@@ -1520,11 +1547,66 @@ static int run_one_chain(rsb_ctx *const *ctx, size_t nch) {
         if (!one_stream || i == last) HIP_TRY(ctx[i], hipStreamWaitEvent(s, ctx[i]->collect_slot().ev[3], 0));
     rsb_slot &b0 = c0->collect_slot();
     HIP_TRY(c0, hipEventRecord(b0.rev[0], s));
+    {
+        // the tables of the channels whose filter moved outside the device replay: the small updates (mirror_filter's first case)
+        // together -- one upload, two launches; a channel whose tables must be rebuilt from scratch goes by itself
+        std::vector<size_t> dirty;
+        size_t words = 0;
+        for (size_t i = 0; i < nch; ++i) {
+            rsb_ctx *c = ctx[i];
+            if (!c->filter_dirty) continue;
+            if (!c->tables_valid || c->table_members.size() > 6 * IcaoFilter::kSlots) {
+                const int rc = mirror_filter(c, s);
+                if (rc != RSB_OK) return rc;
+                continue;
+            }
+            c->replay.filter().contents(c->h_addrs);
+            words += c->h_addrs.size() + c->table_members.size();
+            dirty.push_back(i);
+        }
+        if (!dirty.empty()) {
+            const size_t head = (dirty.size() * sizeof(FilterUpdate) + 15) / 16 * 4;  // words
+            if (head + words > c0->mirror_cap) {
+                if (c0->d_mirror) (void)hipFree(c0->d_mirror);
+                if (c0->h_mirror) (void)hipHostFree(c0->h_mirror);
+                c0->d_mirror = c0->h_mirror = nullptr;
+                c0->mirror_cap = 0;
+                const size_t cap = 2 * (head + words) + 4096;
+                HIP_TRY(c0, hipMalloc((void **)&c0->d_mirror, cap * sizeof(uint32_t)));
+                HIP_TRY(c0, hipHostMalloc((void **)&c0->h_mirror, cap * sizeof(uint32_t), hipHostMallocDefault));
+                c0->mirror_cap = cap;
+            }
+            // (the staging is free: every call of this function ends with a wait for the stream)
+            FilterUpdate *u = (FilterUpdate *)c0->h_mirror;
+            size_t at = head;
+            uint32_t max_stale = 0, max_members = 0;
+            for (size_t k = 0; k < dirty.size(); ++k) {
+                rsb_ctx *c = ctx[dirty[k]];
+                const size_t ns = c->table_members.size(), nm = c->h_addrs.size();
+                u[k].t0 = c->d_first_add[0];
+                u[k].t1 = c->d_first_add[1];
+                u[k].stale = c0->d_mirror + at;
+                u[k].n_stale = (uint32_t)ns;
+                if (ns) std::memcpy(c0->h_mirror + at, c->table_members.data(), ns * sizeof(uint32_t));
+                at += ns;
+                u[k].members = c0->d_mirror + at;
+                u[k].n_members = (uint32_t)nm;
+                if (nm) std::memcpy(c0->h_mirror + at, c->h_addrs.data(), nm * sizeof(uint32_t));
+                at += nm;
+                max_stale = std::max(max_stale, (uint32_t)ns);
+                max_members = std::max(max_members, (uint32_t)nm);
+                c->table_members = c->h_addrs;
+                c->tables_valid = true;
+                c->first_cur = 0;
+                c->filter_dirty = false;
+            }
+            HIP_TRY(c0, hipMemcpyAsync(c0->d_mirror, c0->h_mirror, at * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            HIP_TRY(c0, launch_filter_update_many((const FilterUpdate *)c0->d_mirror, (uint32_t)dirty.size(), max_stale, max_members, s));
+        }
+    }
     for (size_t i = 0; i < nch; ++i) {
         rsb_ctx *c = ctx[i];
         rsb_slot &b = c->collect_slot();
-        int rc;
-        if (c->filter_dirty && (rc = mirror_filter(c, s)) != RSB_OK) return rc;
         b.pruned = true;
         b.pruned_in_order = true;  // (chain_needs_no_host: prune_is_ordered)
         c->sorted_buf = 0;

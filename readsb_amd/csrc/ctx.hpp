@@ -40,6 +40,7 @@ struct rsb_slot {
     const rsb_slot *time_from = nullptr;  // ... and its stage times are in that slot's events
     rsb::ReplayArgs chain_r;
     bool pending = false;
+    bool scan_timed = true, ac_timed = true;  // ev[0..1] / ev[2] were recorded for this batch (not for every channel of a one-launch submit)
     uint64_t submit_seq = 0;  // the order in which the batches of all contexts were submitted
     float scan_share = 1.0f;  // rsb_submit_many: this channel's share of the one scan launch (timing.scan_ms)
     const double *means_on_device = nullptr;  // per-block (mean_level, mean_power) of the pending batch, when taken from float means
@@ -156,6 +157,8 @@ struct rsb_ctx {
     hipStream_t copy_stream = nullptr;    // the finished record list leaves on this one (a DMA copy beside whatever the kernels do)
     bool defer_copy_wait = false;         // rsb_collect_begin: leave the record copy in flight ...
     bool copy_in_flight = false;          // ... until rsb_collect_wait (or the next call that needs the copy stream idle)
+    hipEvent_t reset_done = nullptr;      // behind rsb_reset's clearing of the bitmap on the replay stream
+    bool reset_pending = false;           // ... which the next scan has not been made to wait for yet
     hipEvent_t copy_done = nullptr;       // behind the last record copy on the copy stream
     const rsb_slot *copy_slot = nullptr;  // the slot whose d_out that copy reads: a chain that writes it again waits for copy_done
     hipStream_t replay_stream = nullptr;  // sort / replay / copy-out run here, behind the batch's scan (event) and beside the next one's
@@ -183,6 +186,8 @@ struct rsb_ctx {
     rsb::ChainArgs *d_chain_args = nullptr, *h_chain_args = nullptr;  // rsb_collect_many: the channels' chain arguments (held by the first channel)
     uint32_t *d_chain_back = nullptr, *h_chain_back = nullptr;        // ... and what comes back of every channel, gathered
     size_t chain_args_cap = 0, chain_back_cap = 0;
+    uint32_t *d_mirror = nullptr, *h_mirror = nullptr;  // ... and the table updates of the channels whose filter moved (FilterUpdate headers, then address lists)
+    size_t mirror_cap = 0;  // words
     size_t merge_cap = 0;
 
     // grid_limit: the scan workgroups this batch may have (0 = the context's scan_grid; rsb_submit_many gives every channel its share)

@@ -3232,6 +3232,27 @@ hipError_t launch_scan_many(int fmt, const BatchArgs *args_dev, uint32_t nbatche
     });
 }
 
+// what rsb_submit's memsets and carry copy do, for every batch of a launch_scan_many at once (64 memsets and 32 copies otherwise)
+__global__ __launch_bounds__(kThreads) void k_submit_prepare_many(const BatchArgs *__restrict__ args) {
+    const BatchArgs &a = args[blockIdx.y];
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < (uint32_t)kCntAlloc) a.counters[i] = 0;
+    for (uint32_t r = i; r < a.n_regions; r += gridDim.x * kThreads) a.region_counts[r] = 0;
+    if (a.carry_out && a.n >= (uint64_t)kTrailing) {  // sdr_ifile.c:199-201: the next batch starts with this one's last 326 samples
+        const uint32_t halves = (a.fmt == kFmtUC8 || a.fmt == kFmtMag16) ? kTrailing : 2 * kTrailing;  // 16-bit units
+        const uint16_t *src = (const uint16_t *)a.iq + (a.n - kTrailing) * (halves / kTrailing);
+        for (uint32_t k = i; k < halves; k += gridDim.x * kThreads) ((uint16_t *)a.carry_out)[k] = src[k];
+    }
+}
+hipError_t launch_submit_prepare_many(const BatchArgs *args_dev, uint32_t nbatches, uint32_t max_regions, hipStream_t s) {
+    if (nbatches == 0) return hipSuccess;
+    unsigned gx = (max_regions + kThreads - 1) / kThreads;
+    if (gx < 1) gx = 1;
+    if (gx > 4) gx = 4;
+    hipLaunchKernelGGL(k_submit_prepare_many, dim3(gx, nbatches), dim3(kThreads), 0, s, args_dev);
+    return hipGetLastError();
+}
+
 hipError_t launch_prune(const BatchArgs &a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_prune, dim3(a.n_regions + 1), dim3(kThreads), 0, s, a);
@@ -3495,6 +3516,23 @@ __global__ __launch_bounds__(kThreads) void k_filter_clear(uint32_t *t0, uint32_
 hipError_t launch_filter_update(uint32_t *t0, uint32_t *t1, const uint32_t *stale_dev, uint32_t n_stale, const uint32_t *addrs_dev, uint32_t n, hipStream_t s) {
     if (n_stale) hipLaunchKernelGGL(k_filter_clear, dim3((n_stale + kThreads - 1) / kThreads), dim3(kThreads), 0, s, t0, t1, stale_dev, n_stale);
     hipLaunchKernelGGL(k_filter_fill, dim3((n + kThreads) / kThreads), dim3(kThreads), 0, s, t0, t1, addrs_dev, n);  // (also sets entry 0)
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(kThreads) void k_filter_clear_many(const FilterUpdate *__restrict__ u) {
+    const FilterUpdate &f = u[blockIdx.y];
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < f.n_stale; i += gridDim.x * kThreads) f.t0[f.stale[i]] = f.t1[f.stale[i]] = kNever;
+}
+__global__ __launch_bounds__(kThreads) void k_filter_fill_many(const FilterUpdate *__restrict__ u) {
+    const FilterUpdate &f = u[blockIdx.y];
+    if (blockIdx.x == 0 && threadIdx.x == 0) f.t0[0] = f.t1[0] = 0;  // icaoFilterTest(0) hits an empty slot (icao_filter.c:101-107)
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < f.n_members; i += gridDim.x * kThreads) f.t0[f.members[i]] = f.t1[f.members[i]] = 0;
+}
+hipError_t launch_filter_update_many(const FilterUpdate *u_dev, uint32_t nch, uint32_t max_stale, uint32_t max_members, hipStream_t s) {
+    if (nch == 0) return hipSuccess;
+    const auto grid = [](uint32_t n) { const unsigned g = (n + kThreads - 1) / kThreads; return g < 1 ? 1u : (g > 64 ? 64u : g); };
+    if (max_stale) hipLaunchKernelGGL(k_filter_clear_many, dim3(grid(max_stale), nch), dim3(kThreads), 0, s, u_dev);
+    hipLaunchKernelGGL(k_filter_fill_many, dim3(grid(max_members), nch), dim3(kThreads), 0, s, u_dev);
     return hipGetLastError();
 }
 

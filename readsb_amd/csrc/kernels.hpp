@@ -113,6 +113,7 @@ struct BatchArgs {
     int debug_flags;         // ablation only (RSB_ABL): 1 skip classify, 2 skip slicing loads, 4 skip reductions
     int stage_limit;         // debug/ablation only (RSB_STAGE_LIMIT): stop the scan kernel after stage k
     uint32_t block_len;      // samples per demodulator call (mag_buf.length of a full buffer): 131072 unless the source builds other buffers
+    void *carry_out;         // rsb_submit_many's one launch: where the batch's last 326 samples go (the next batch's carry), or null
     uint64_t *wave_times;    // debug only (RSB_WAVE_TIMES): per scan wavefront {start, end (100 MHz ticks), XCC id << 32 | HW_ID, strips taken}
 };
 
@@ -164,6 +165,8 @@ int scan_grid_size(int device);
 hipError_t launch_scan(const BatchArgs &a, int grid, hipStream_t s);
 // nbatches batches of one format in one launch: args_dev[i] built for groups_per_batch workgroups (n_regions = 16 x that), n = 0 allowed
 hipError_t launch_scan_many(int fmt, const BatchArgs *args_dev, uint32_t nbatches, uint32_t groups_per_batch, hipStream_t s);
+// in front of launch_scan_many: every batch's counters and region counts to zero and its carry_out filled, in one launch
+hipError_t launch_submit_prepare_many(const BatchArgs *args_dev, uint32_t nbatches, uint32_t max_regions, hipStream_t s);
 hipError_t launch_prune(const BatchArgs &a, hipStream_t s);
 hipError_t launch_prune_ordered(const BatchArgs &a, hipStream_t s);
 // sorts the n_items kept items by (g, phase), derives the ascending list of distinct offsets
@@ -183,6 +186,14 @@ hipError_t launch_replay_select(const BatchArgs &a, const ReplayArgs &r, void *t
 hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream_t s);
 // (launch_replay_select leaves the tables alone; this folds the batch's new members into them once the fixed point is certain)
 hipError_t launch_replay_fold(const ReplayArgs &r, hipStream_t s);
+// The first-add tables of several channels brought up to their host filters in two launches (entries listed in stale -> "never",
+// then entries listed in members, and entry 0, -> "in the filter before the batch"); u_dev[i] holds device pointers
+struct FilterUpdate {
+    uint32_t *t0, *t1;
+    const uint32_t *stale, *members;
+    uint32_t n_stale, n_members;
+};
+hipError_t launch_filter_update_many(const FilterUpdate *u_dev, uint32_t nch, uint32_t max_stale, uint32_t max_members, hipStream_t s);
 // The whole chain for several channels' batches, one launch per stage (kernels.hip "the *_many forms"): the ordered prune, then
 // bounds / seed / score / walk / adds / compare / places / list / records / fold-if-converged, then every channel's
 // [changed | counters | block counts | first pin_adders new adders] gathered to readback_dev + i * readback_stride (words).
