@@ -299,6 +299,12 @@ def main() -> int:
                                 max_batch_samples=max(b - a for a, b in zip(cuts, cuts[1:])), queue_div=16 if args.dense else 32,
                                 scan_workgroups=scan_wgs)
              for _ in range(2 if overlap else C)]
+    # ... and with several channels: two sets of C channels take the steps in turn (rsb_collect_many_begin: a step's records cross PCIe
+    # while the other set's scans run)
+    overlap_many = args.steps_in_flight == 2 and C > 1 and not args.dcfilter
+    chans2 = [readsb_amd.Channel(fmt=args.format, fix_bits=args.fix_bits, mode_ac=args.modeac, dc_filter=args.dcfilter, device=local_rank,
+                                 max_batch_samples=max(b - a for a, b in zip(cuts, cuts[1:])), queue_div=16 if args.dense else 32,
+                                 scan_workgroups=scan_wgs) for _ in range(C if overlap_many else 0)]
     ch = chans[0]
     stream = torch.cuda.current_stream().cuda_stream
     cap = max(1 << 16, n // (256 if args.dense else 512))
@@ -355,7 +361,8 @@ def main() -> int:
             for c in chans:
                 t = c.timing()
                 for k in keys:
-                    acc[k] = min(acc[k], t[k]) if k == "replay_on_device" else max(acc[k], t[k]) if k == "replay_iterations" else acc[k] + t[k]
+                    acc[k] = min(acc[k], t[k]) if k == "replay_on_device" else \
+                        max(acc[k], t[k]) if k in ("replay_iterations", "prune_ms", "device_replay_ms") else acc[k] + t[k]
         if tm is not None:
             for k in keys:
                 tm[k].append(acc[k])
@@ -366,8 +373,45 @@ def main() -> int:
     def barrier():
         rd.barrier(dev)
 
-    outbuf2 = torch.empty(cap * readsb_amd.MSG_DTYPE.itemsize if overlap else 1, dtype=torch.uint8, pin_memory=True).numpy().view(
-        readsb_amd.MSG_DTYPE if overlap else np.uint8)
+    outbuf2 = torch.empty(cap * readsb_amd.MSG_DTYPE.itemsize if overlap or overlap_many else 1, dtype=torch.uint8, pin_memory=True).numpy().view(
+        readsb_amd.MSG_DTYPE if overlap or overlap_many else np.uint8)
+
+    def steps_overlapped_many(count, tm=None):
+        """count steps of C channels each, every step all C recordings from cold filters, on the set of channels whose turn it is.  A
+        step's record copies (rsb_collect_many_begin .. rsb_collect_wait) run beside the next step's scans; everything else as in
+        step().  Returns the last step's lists (complete: the last waits are inside)."""
+        sets, bufs, per = (chans, chans2), (outbuf, outbuf2), cap // C
+        ptrs, lens = [base + bps * nc * i for i in range(C)], [nc] * C
+        for c in sets[0]:
+            c.reset()
+        readsb_amd.submit_many(sets[0], ptrs, lens, stream)
+        views = None
+        for k in range(count):
+            mine, other = sets[k % 2], sets[(k + 1) % 2]
+            if k > 0:
+                for c in other:
+                    c.collect_wait()               # step k - 1's records are in host memory
+            if k + 1 < count:
+                for c in other:
+                    c.reset()
+            views = readsb_amd.collect_many(mine, [bufs[k % 2][i * per:(i + 1) * per] for i in range(C)], wait=False)
+            if k + 1 < count:
+                readsb_amd.submit_many(other, ptrs, lens, stream)
+            if tm is not None:
+                acc = {key: 0.0 for key in keys}
+                acc["replay_on_device"] = 1
+                for c in mine:
+                    t = c.timing()
+                    for key in keys:
+                        # (prune / replay: the one chain all channels share reports the same times on every channel)
+                        acc[key] = min(acc[key], t[key]) if key == "replay_on_device" else \
+                            max(acc[key], t[key]) if key in ("replay_iterations", "prune_ms", "device_replay_ms") else acc[key] + t[key]
+                for key in keys:
+                    tm[key].append(acc[key])
+        for c in sets[(count - 1) % 2]:
+            c.collect_wait()
+        chan_msgs[1] = views[0].size
+        return views
 
     def steps_overlapped(count, tm=None):
         """count steps, every one the whole recording from a cold filter on the receiver channel whose turn it is (two channels, two
@@ -409,12 +453,16 @@ def main() -> int:
         msgs = step()
         if overlap:
             msgs = steps_overlapped(2)
+        if overlap_many:
+            msgs = steps_overlapped_many(2)
     tm = {k: [] for k in keys}
     scan_ms = tm["scan_ms"]
     barrier()
     t0 = time.perf_counter()
     if overlap:
         msgs = steps_overlapped(args.steps, tm)
+    elif overlap_many:
+        msgs = steps_overlapped_many(args.steps, tm)
     else:
         for _ in range(args.steps):
             msgs = step(tm)
@@ -423,7 +471,7 @@ def main() -> int:
     if isinstance(msgs, list):
         msgs = np.concatenate(msgs)
     serial_ms = None
-    if overlap:  # for the record, outside the timed region: the same steps one at a time (submit -> collect latency of one recording)
+    if overlap or overlap_many:  # for the record, outside the timed region: the same steps one at a time (submit -> collect latency of one recording)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(2):
@@ -505,7 +553,7 @@ def main() -> int:
                        "samples_per_gpu": n, "segment_samples": seg_n, "format": args.format, "fix_bits": args.fix_bits,
                        "mode_ac": bool(args.modeac), "dc_filter": bool(args.dcfilter),
                        "batches_per_step": len(cuts) - 1, "batches_in_flight": min(args.in_flight, len(cuts) - 1), "scan_workgroups": scan_wgs or "all",
-                       "steps_in_flight": 2 if overlap else 1,
+                       "steps_in_flight": 2 if overlap or overlap_many else 1,
                        **({"ms_per_step_one_at_a_time": serial_ms} if serial_ms is not None else {}),
                        "channels": world * C, "channels_per_gpu": C, "messages_per_step": nmsgs, "survivors_per_step": st["survivors"],
                        "full_size_check": parity, "oracle_check": oracle_check, "ranks_with_checks_ok": checks_ok, "output": args.output,

@@ -244,10 +244,21 @@ int rsb_collect_prepare(rsb_ctx *ctx);
  * When the channels are distinct plain contexts of one device and format (no dc_filter, no RSB_FLAG_SC16Q11_TABLE), and there are
  * at most as many as the scan has workgroups, their scans are ONE kernel launch: every channel gets an equal share of the
  * workgroups and its wavefronts walk a long run of that channel's samples, where a channel of a few ten Msamples alone would pay
- * the kernel's set-up and ramp for two or three strips per wavefront (8.0 instead of 9.3 ms for 32 x 32 Msamples).  Nothing is
- * submitted then unless every channel can be; rsb_timing.scan_ms of a channel is its share (by samples) of that launch. */
+ * the kernel's set-up and ramp for two or three strips per wavefront.  Nothing is submitted then unless every channel can be; the
+ * launch is timed once: rsb_timing.scan_ms is the whole launch on ctx[0] and 0 on the other channels.
+ * Likewise rsb_collect_many: when every channel's batch is of the usual kind (no host replay, no exact statistics, no deferred
+ * prune, nothing of it prepared yet), the prune / replay / emit chains of all channels are ONE chain of launches on ctx[0]'s
+ * stream (every kernel takes all channels, one channel per blockIdx.y) with one host wait, and the filter tables of the channels
+ * whose filter moved from outside are brought up to date together.  A channel whose first replay round was not the fixed point
+ * (rare) goes on by itself behind the shared chain.  rsb_timing.prune_ms / device_replay_ms are then the shared chain's, the same
+ * on every channel.  32 channels x 32 Msamples: 3.3 ms per call pair instead of 8.0 (profiles/r3_bench_channels32_*.json).
+ * rsb_collect_many_begin is rsb_collect_many without the last step, the wait for the record copies: it returns when every
+ * channel's n_out is known and its copy is under way, and the caller ends each channel with rsb_collect_wait (before reading
+ * out[i]) -- meanwhile it can submit the next batches, whose scans then run beside the copies (as rsb_collect_begin does for one
+ * channel). */
 int rsb_submit_many(rsb_ctx *const *ctx, size_t nch, const void *const *iq_dev, const uint64_t *nsamples, void *stream);
 int rsb_collect_many(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, const size_t *cap, size_t *n_out);
+int rsb_collect_many_begin(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, const size_t *cap, size_t *n_out);
 
 /* Device-side ordering without the host: work enqueued on `stream` after this call starts only when the chain that
  * rsb_collect_prepare put on the context's own stream has finished (without a prepared chain: when the batch's scan has).  For a

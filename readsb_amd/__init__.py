@@ -99,6 +99,7 @@ SYMBOLS = {
     "rsb_collect_fence": (C.c_int, [_VP, _VP]),
     "rsb_submit_many": (C.c_int, [_VP, _SZ, _VP, _VP, _VP]),
     "rsb_collect_many": (C.c_int, [_VP, _SZ, _VP, _VP, _VP]),
+    "rsb_collect_many_begin": (C.c_int, [_VP, _SZ, _VP, _VP, _VP]),
     "rsb_process": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_process_host": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_get_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
@@ -167,14 +168,15 @@ def submit_many(chans, dev_ptrs, nsamples, stream: int = 0):
         raise RsbError(f"rsb_submit_many: {rc}")
 
 
-def collect_many(chans, outs):
-    """rsb_collect_many: outs[i] = a (pinned) MSG_DTYPE array per channel -> list of views holding each channel's messages"""
+def collect_many(chans, outs, wait=True):
+    """rsb_collect_many: outs[i] = a (pinned) MSG_DTYPE array per channel -> list of views holding each channel's messages.
+    wait=False: rsb_collect_many_begin -- the record copies are still under way; Channel.collect_wait() on every channel before reading"""
     n = len(chans)
     ctx = (_VP * n)(*[c.h for c in chans])
     op = (_VP * n)(*[o.ctypes.data for o in outs])
     cap = (_SZ * n)(*[o.size for o in outs])
     cnt = (_SZ * n)()
-    rc = chans[0].l.rsb_collect_many(ctx, n, op, cap, cnt)
+    rc = (chans[0].l.rsb_collect_many if wait else chans[0].l.rsb_collect_many_begin)(ctx, n, op, cap, cnt)
     if rc != 0:
         raise RsbError(f"rsb_collect_many: {rc}")
     return [o[:int(k)] for o, k in zip(outs, cnt)]

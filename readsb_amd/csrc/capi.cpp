@@ -1619,7 +1619,10 @@ static int run_one_chain(rsb_ctx *const *ctx, size_t nch) {
         b.h_pin[0] = 0;
         c0->h_chain_args[i].a = b.pending_args;
         c0->h_chain_args[i].r = r;
-        const BatchArgs &a = b.pending_args;
+        // Many channels' bitmaps together do not stay in the L2s (2 MiB each): the prune then looks into each channel's hashed 4 KB
+        // summary first, which a single small batch does not bother to build (rsb_ctx::summary_from)
+        if (nch >= 4 && c->d_summary && !std::getenv("RSB_NO_CHAIN_SUMMARY")) c0->h_chain_args[i].a.adder_summary = c->d_summary;
+        const BatchArgs &a = c0->h_chain_args[i].a;
         if (a.n) {
             d.max_regions = std::max(d.max_regions, a.n_regions);
             d.max_chunks = std::max(d.max_chunks, a.n_chunks);
@@ -1664,7 +1667,17 @@ static int run_one_chain(rsb_ctx *const *ctx, size_t nch) {
     return RSB_OK;
 }
 
+static int collect_many_impl(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, const size_t *cap, size_t *n_out, bool wait_for_copies);
+
 int rsb_collect_many(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, const size_t *cap, size_t *n_out) {
+    return collect_many_impl(ctx, nch, out, cap, n_out, true);
+}
+
+int rsb_collect_many_begin(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, const size_t *cap, size_t *n_out) {
+    return collect_many_impl(ctx, nch, out, cap, n_out, false);
+}
+
+static int collect_many_impl(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, const size_t *cap, size_t *n_out, bool wait_for_copies) {
     if (!ctx || !out || !cap || !n_out) return RSB_EINVAL;
     for (size_t i = 0; i < nch; ++i)
         if (!ctx[i] || (!out[i] && cap[i])) return RSB_EINVAL;
@@ -1698,7 +1711,7 @@ int rsb_collect_many(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, c
         }
         // ... which that channel's own stream knows nothing of: wait for it here (rare)
         if (tail_on_shared_stream && hipStreamSynchronize(s) != hipSuccess && first == RSB_OK) first = RSB_ENODEV;
-        for (size_t i = 0; i < nch; ++i) {
+        for (size_t i = 0; i < nch && (wait_for_copies || (first != RSB_OK && first != RSB_EOVERFLOW)); ++i) {
             rc = rsb_collect_wait(ctx[i]);
             if (rc != RSB_OK && first == RSB_OK) first = rc;
         }
@@ -1715,7 +1728,7 @@ int rsb_collect_many(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, c
         const int rc = rsb_collect_begin(ctx[i], out[i], cap[i], &n_out[i]);
         if (rc != RSB_OK && first == RSB_OK) first = rc;
     }
-    for (size_t i = 0; i < nch; ++i) {
+    for (size_t i = 0; i < nch && (wait_for_copies || (first != RSB_OK && first != RSB_EOVERFLOW)); ++i) {
         const int rc = rsb_collect_wait(ctx[i]);
         if (rc != RSB_OK && first == RSB_OK) first = rc;
     }
