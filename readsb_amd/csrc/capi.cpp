@@ -101,7 +101,11 @@ int setup_device(rsb_ctx *c) {
     }
     // --dcfilter (and the SC16Q11 table converter) keeps one magnitude buffer, which the replay of a batch still reads: one batch in flight there
     c->q11_table_bits = (int)RSB_FLAG_SC16Q11_TABLE_BITS_OF(c->cfg.flags);
-    c->nslots = (c->cfg.dc_filter || c->q11_table_bits) ? 1 : rsb_ctx::kMaxSlots;
+    // ... unless the kernels filter for themselves (16-bit formats, Mode S only, no exact statistics: those two take the converter's
+    // block means): then a batch's filter states live in its slot and batches overlap as without the filter
+    c->dc_fused = c->cfg.dc_filter && !c->q11_table_bits && (c->cfg.input_format == RSB_SC16 || c->cfg.input_format == RSB_SC16Q11) && !c->run_ac &&
+                  !c->exact_stats && !std::getenv("RSB_DC_UNFUSED");
+    c->nslots = c->dc_fused ? 2 : ((c->cfg.dc_filter || c->q11_table_bits) ? 1 : rsb_ctx::kMaxSlots);
     for (int k = 0; k < c->nslots; ++k) {
         rsb_slot &b = c->slots[k];
         HIP_TRY(c, hipMalloc((void **)&b.d_items, (size_t)c->item_cap * sizeof(ItemRec)));
@@ -136,11 +140,20 @@ int setup_device(rsb_ctx *c) {
     if (c->mean_sub) HIP_TRY(c, hipMalloc((void **)&c->d_sub_means, ((size_t)(nmax / c->mean_sub) + 2) * 2 * sizeof(double)));
     HIP_TRY(c, hipMalloc((void **)&c->d_dc_state, sizeof(double2)));
     HIP_TRY(c, hipMemset(c->d_dc_state, 0, sizeof(double2)));
-    if (c->cfg.dc_filter || c->q11_table_bits) HIP_TRY(c, hipMalloc((void **)&c->d_magbuf, (size_t)nmax * sizeof(uint16_t) + 16));
+    if ((c->cfg.dc_filter && !c->dc_fused) || c->q11_table_bits) HIP_TRY(c, hipMalloc((void **)&c->d_magbuf, (size_t)nmax * sizeof(uint16_t) + 16));
     if (c->cfg.dc_filter) {
         c->dc_tiles_cap = (size_t)((nmax + kDcTileSamples - 1) / kDcTileSamples) + 1;
         HIP_TRY(c, hipMalloc((void **)&c->d_dc_tile_sums, c->dc_tiles_cap * sizeof(double2)));
         HIP_TRY(c, hipMalloc((void **)&c->d_dc_tile_start, c->dc_tiles_cap * sizeof(double2)));
+    }
+    if (c->dc_fused) {
+        double pw[512];
+        dc_pow_table(pw);
+        if ((rc = upload(c, &c->d_dc_pow, pw, 512)) != RSB_OK) return rc;
+        for (int k = 0; k < c->nslots; ++k) {
+            HIP_TRY(c, hipMalloc((void **)&c->slots[k].d_dc_local, c->dc_tiles_cap * (kDcTileSamples / 8) * sizeof(float2)));
+            HIP_TRY(c, hipMalloc((void **)&c->slots[k].d_dc_tile_start, c->dc_tiles_cap * sizeof(double2)));
+        }
     }
     c->host_replay_only = (c->cfg.flags & (RSB_FLAG_HOST_REPLAY | RSB_FLAG_EXACT_STATS)) != 0;
     if (!c->host_replay_only) {
@@ -579,6 +592,12 @@ void rsb_destroy(rsb_ctx *c) {
     }
     if (c->replay_stream) (void)hipStreamDestroy(c->replay_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (rsb_slot &b : c->slots) {
+        if (b.d_dc_local) (void)hipFree(b.d_dc_local);
+        if (b.d_dc_tile_start) (void)hipFree(b.d_dc_tile_start);
+    }
+    if (c->d_dc_pow) (void)hipFree(c->d_dc_pow);
+    if (c->d_dc_mags) (void)hipFree(c->d_dc_mags);
     for (void *p : c->d_carry)
         if (p) (void)hipFree(p);
     for (void *p : ptrs)
@@ -827,7 +846,9 @@ static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint6
         // the next batch's 326-sample overlap (sdr_ifile.c:199-201)
         const unsigned bps = (a.fmt == kFmtUC8 || a.fmt == kFmtMag16) ? 2 : 4;
         const unsigned k = (c->submitted + 1) % rsb_ctx::kCarries;
-        if (!a.carry_out)  // (else the one launch's prepare kernel has copied it)
+        if (a.dc_local)  // the DC block inside the scan: the next batch's overlap as magnitudes (the filter's states of this batch do not outlive its slot)
+            HIP_TRY(c, launch_dc_carry(a, (uint16_t *)c->d_carry[k], s));
+        else if (!a.carry_out)  // (else the one launch's prepare kernel has copied it)
             HIP_TRY(c, hipMemcpyAsync(c->d_carry[k], (const char *)a.iq + (nsamples - kTrailing) * bps, (size_t)kTrailing * bps, hipMemcpyDeviceToDevice, s));
         c->carry_valid[k] = 1;
     }
@@ -871,6 +892,22 @@ int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) 
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     rsb_slot &b = c->submit_slot();
     hipStream_t s = (hipStream_t)stream;
+    if (c->reset_pending) {  // (the converters below run in front of enqueue_before_scan, which waits for this otherwise)
+        HIP_TRY(c, hipStreamWaitEvent(s, c->reset_done, 0));
+        c->reset_pending = false;
+    }
+    if (c->dc_fused) {
+        // --dcfilter, 16-bit formats: one pass over the IQ leaves the filter's state before every 8-sample chunk; the scan (and
+        // whatever else needs a magnitude) takes the samples through the filter itself.  No magnitude touches memory.
+        HIP_TRY(c, launch_dc_states(c->cfg.input_format, iq_dev, nsamples, c->d_dc_tile_sums, b.d_dc_tile_start, b.d_dc_local, c->d_dc_state, s));
+        BatchArgs a = c->batch_args(b, iq_dev, nsamples, c->cfg.input_format);
+        a.dc_local = b.d_dc_local;
+        a.dc_tile_start = b.d_dc_tile_start;
+        a.dc_pow = c->d_dc_pow;
+        dc_coefficients(&a.dc_a, &a.dc_b);
+        a.carry_is_mag = 1;
+        return enqueue_batch(c, b, a, nsamples, s);
+    }
     if (c->cfg.dc_filter) {
         // --dcfilter: the chunked-scan converter writes the batch's magnitudes; the scan reads those (carry = the previous batch's last 326)
         const bool want_means = c->run_ac || c->exact_stats;
@@ -992,6 +1029,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     b.pending = false;
     ++c->collected;
     c->last_n = b.pending_n;
+    c->last_args = b.pending_args;
     c->last_list_dev = nullptr;
     c->last_items_info = nullptr;
     c->last_g0 = b.g0;
@@ -1769,11 +1807,25 @@ int rsb_process_host(rsb_ctx *c, const void *iq_host, uint64_t nsamples, rsb_mes
 
 int rsb_get_batch_magnitudes(rsb_ctx *c, uint16_t *mag_host, uint64_t nsamples, double *block_means) {
     if (!c || !mag_host) return RSB_EINVAL;
-    if (!c->d_magbuf || c->any_pending() || nsamples > c->last_n) {
+    if ((!c->d_magbuf && !c->dc_fused) || c->any_pending() || nsamples > c->last_n) {
         c->err = "rsb_get_batch_magnitudes: only after rsb_collect on a --dcfilter or RSB_FLAG_SC16Q11_TABLE context, at most the batch's samples";
         return RSB_ESTATE;
     }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (c->dc_fused) {
+        // no magnitude buffer exists: the batch's magnitudes are made now, from the batch's samples (still the caller's to keep valid)
+        // and the filter states in its slot, by the routine every kernel of the batch used
+        if (nsamples * sizeof(uint16_t) > c->dc_mags_cap) {
+            if (c->d_dc_mags) (void)hipFree(c->d_dc_mags);
+            c->d_dc_mags = nullptr;
+            c->dc_mags_cap = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_dc_mags, nsamples * sizeof(uint16_t) + 16));
+            c->dc_mags_cap = nsamples * sizeof(uint16_t);
+        }
+        HIP_TRY(c, launch_dc_materialize(c->last_args, c->d_dc_mags, nullptr));
+        HIP_TRY(c, hipMemcpy(mag_host, c->d_dc_mags, (size_t)nsamples * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        return RSB_OK;
+    }
     HIP_TRY(c, hipMemcpy(mag_host, c->d_magbuf, (size_t)nsamples * sizeof(uint16_t), hipMemcpyDeviceToHost));
     if (block_means && c->run_ac) {
         const size_t nblk = (size_t)((c->last_n + c->block_len - 1) / c->block_len);

@@ -40,6 +40,8 @@ struct rsb_slot {
     const rsb_slot *time_from = nullptr;  // ... and its stage times are in that slot's events
     rsb::ReplayArgs chain_r;
     bool pending = false;
+    float2 *d_dc_local = nullptr;     // the DC block inside the scan: the filter's per-chunk states of this slot's batch (kernels.hpp: BatchArgs::dc_local)
+    double2 *d_dc_tile_start = nullptr;
     bool scan_timed = true, ac_timed = true;  // ev[0..1] / ev[2] were recorded for this batch (not for every channel of a one-launch submit)
     uint64_t submit_seq = 0;  // the order in which the batches of all contexts were submitted
     float scan_share = 1.0f;  // rsb_submit_many: this channel's share of the one scan launch (timing.scan_ms)
@@ -134,6 +136,11 @@ struct rsb_ctx {
     int q11_table_bits = 0;  // RSB_FLAG_SC16Q11_TABLE: the converter of a reference built with -DSC16Q11_TABLE_BITS (0 = the float one)
     double2 *d_dc_tile_sums = nullptr, *d_dc_tile_start = nullptr, *d_dc_state = nullptr;
     size_t dc_tiles_cap = 0;
+    bool dc_fused = false;            // --dcfilter without a magnitude buffer: SC16 / SC16Q11, Mode S only (the scan, the candidate and the record kernels filter for themselves)
+    double *d_dc_pow = nullptr;
+    uint16_t *d_dc_mags = nullptr;    // rsb_get_batch_magnitudes on such a context: the last batch's magnitudes, made on request
+    size_t dc_mags_cap = 0;
+    rsb::BatchArgs last_args;         // of the last collected batch
 
     // drop-in block mode (dropin.cpp): every call is one struct mag_buf -- magnitudes in, overlap included
     bool block_mode = false;

@@ -109,14 +109,66 @@ __device__ __forceinline__ uint32_t mag_of(const void *base, uint64_t i, const u
     }
 }
 
-// S[s] of the batch stream S = carry(326) ++ iq(n); zero outside
+// ---- the DC block (convert.c:113-162) inside the kernels that read raw IQ.  A pass in front of the scan (launch_dc_states) leaves
+// the filter's state before every 8-sample chunk -- evaluated as a chunked scan in double, as the converter kernel does -- and the
+// chunk's samples then go through the reference's own float recurrence from that state.  Every kernel that needs a magnitude
+// (scan, general strips, candidate records, message records, carry) computes it this way, so all of them see the same values.
+__device__ __forceinline__ float2 dc_state_before_chunk(const BatchArgs &a, uint64_t chunk) {
+    const float2 l = a.dc_local[chunk];
+    const double2 z0 = a.dc_tile_start[chunk >> 9];
+    const double p = a.dc_pow[chunk & 511u];
+    return make_float2((float)((double)l.x + z0.x * p), (float)((double)l.y + z0.y * p));
+}
+// one SC16 / SC16Q11 sample through the filter (state z) -> its magnitude
 template <int FMT>
-__device__ __forceinline__ uint32_t stream_mag(const BatchArgs &a, int64_t s) {
+__device__ __forceinline__ uint32_t dc_sample(uint32_t w, float dc_a, float dc_b, float2 &z) {
+    constexpr float scale = (FMT == kFmtSC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);  // exact: a power of two
+    float xI = (float)(short)(w & 0xffffu) * scale, xQ = (float)(short)(w >> 16) * scale;
+    z.x = xI * dc_a + z.x * dc_b;  // convert.c:137-140
+    z.y = xQ * dc_a + z.y * dc_b;
+    xI -= z.x;
+    xQ -= z.y;
+    return float_mag(xI, xQ);
+}
+template <int FMT>
+__device__ __forceinline__ uint4 dc_chunk(const BatchArgs &a, const uint4 x0, const uint4 x1, uint64_t chunk) {  // -> 8 biased magnitudes
+    float2 z = dc_state_before_chunk(a, chunk);
+    const uint32_t W[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    uint32_t m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = dc_sample<FMT>(W[k], a.dc_a, a.dc_b, z) ^ 0x8000u;  // (the LDS arrays' bias, kBias below)
+    return make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
+}
+
+// S[s] of the batch stream S = carry(326) ++ iq(n); zero outside.  The *_run form keeps the DC filter's state between calls for
+// ascending s (zpos = the iq index the state z is valid for; -1: none): one step per sample instead of a walk from the chunk's start.
+template <int FMT>
+__device__ __forceinline__ uint32_t stream_mag_run(const BatchArgs &a, int64_t s, float2 &z, int64_t &zpos) {
     if (s < 0) return 0;
-    if (s < (int64_t)kTrailing) return a.carry_valid ? mag_of<FMT>(a.carry, (uint64_t)s, a.tab.uc8_lut) : 0u;
+    if (s < (int64_t)kTrailing) {
+        if (!a.carry_valid) return 0u;
+        return a.carry_is_mag ? (uint32_t)((const uint16_t *)a.carry)[s] : mag_of<FMT>(a.carry, (uint64_t)s, a.tab.uc8_lut);
+    }
     s -= kTrailing;
     if ((uint64_t)s >= a.n) return 0;
+    if constexpr (FMT == kFmtSC16 || FMT == kFmtSC16Q11) {
+        if (a.dc_local) {
+            const uint32_t *iq = (const uint32_t *)a.iq;
+            if (s != zpos || (s & 7) == 0) {
+                z = dc_state_before_chunk(a, (uint64_t)s >> 3);
+                for (int64_t j = s & ~(int64_t)7; j < s; ++j) (void)dc_sample<FMT>(iq[j], a.dc_a, a.dc_b, z);
+            }
+            zpos = s + 1;
+            return dc_sample<FMT>(iq[s], a.dc_a, a.dc_b, z);
+        }
+    }
     return mag_of<FMT>(a.iq, (uint64_t)s, a.tab.uc8_lut);
+}
+template <int FMT>
+__device__ __forceinline__ uint32_t stream_mag(const BatchArgs &a, int64_t s) {
+    float2 z = make_float2(0.0f, 0.0f);
+    int64_t zpos = -1;
+    return stream_mag_run<FMT>(a, s, z, zpos);
 }
 
 // LDS magnitude arrays hold "biased" magnitudes, mag ^ 0x8000, i.e. mag - 32768 as int16.  The taps of
@@ -769,15 +821,18 @@ __device__ void fill_region_general(const BatchArgs &a, uint16_t *m, int64_t s0,
     for (int v = (int)lane; v < kRegion / 8; v += 64) {
         const int64_t s = s0 + 8 * v;
         uint32_t e[8];
+        float2 z = make_float2(0.0f, 0.0f);
+        int64_t zpos = -1;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) e[k] = stream_mag<FMT>(a, s + k) ^ kBias;
+        for (int k = 0; k < 8; ++k) e[k] = stream_mag_run<FMT>(a, s + k, z, zpos) ^ kBias;
         ((uint4 *)m)[v] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
     }
 }
 
 // The scan of one batch by the workgroups [0, n_regions / 16) given to it; `group` = this workgroup's number among them.
-template <int FMT>
+template <int FMT, bool DC = false>
 __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t group) {
+    static_assert(!DC || FMT == kFmtSC16 || FMT == kFmtSC16Q11, "the DC block inside the scan: 16-bit formats");
     extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
     ScanShared &sh = *reinterpret_cast<ScanShared *>(scan_lds);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform: SGPR
@@ -946,6 +1001,15 @@ __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t gro
                     } else {
                         o = radial_take<0>(rc[t & 1], lut_min);
                     }
+                    ((uint4 *)W.m)[(int)lane + 64 * t] = o;
+                    take_chunk(t, o);
+                }
+            } else if constexpr (DC) {
+                // (an interior strip: its first raw sample is a multiple of 8, so a lane's 8 samples are one chunk of the filter's states)
+                const uint64_t chunk0 = (uint64_t)(((int64_t)((uint64_t)strip * kStrip) - kTileShift - (int64_t)kTrailing) >> 3) + lane;
+#pragma unroll
+                for (int t = 0; t < kPasses; ++t) {
+                    const uint4 o = dc_chunk<FMT>(a, pre[t][0], pre[t][kRawVecs - 1], chunk0 + 64u * (uint32_t)t);
                     ((uint4 *)W.m)[(int)lane + 64 * t] = o;
                     take_chunk(t, o);
                 }
@@ -1306,9 +1370,9 @@ __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t gro
     }
 }
 
-template <int FMT>
+template <int FMT, bool DC = false>
 __global__ __launch_bounds__(kScanThreads) void k_scan(const BatchArgs a) {
-    scan_body<FMT>(a, blockIdx.x);
+    scan_body<FMT, DC>(a, blockIdx.x);
 }
 
 // Many batches (receiver channels) in one launch: batch i has the workgroups [i * groups_per_batch, (i + 1) * groups_per_batch) and its
@@ -2018,7 +2082,9 @@ __device__ __forceinline__ void replay_emit_body(const BatchArgs &a, const Repla
         const int64_t e0 = (int64_t)g + 19 - (int64_t)kTrailing;  // index into iq of the first data sample (may be < 0: the overlap)
         const uint32_t par = (uint32_t)e0 & 1u;
         const int64_t sd = e0 - (int64_t)par;
-        const bool direct = a.iq_aligned && sd >= 0 && sd + 24 * ntrios <= (int64_t)a.n;
+        const bool direct = a.iq_aligned && sd >= 0 && sd + 24 * ntrios <= (int64_t)a.n && !a.dc_local;  // (DC block: through the filter, sample by sample)
+        float2 zrun = make_float2(0.0f, 0.0f);
+        int64_t zpos = -1;
         // (lanes that cannot read their window directly read the head of the UC8 table instead -- always there, 128 KB -- and
         // ignore it: behind a branch the compiler cannot count the loads in flight and waits for ALL of them at every use,
         // refills included, so nothing of the prefetch overlapped anything)
@@ -2052,8 +2118,10 @@ __device__ __forceinline__ void replay_emit_body(const BatchArgs &a, const Repla
                 }
             } else {  // near the ends of the stream, or unaligned input: sample by sample
                 const int64_t s = (int64_t)g + 19 - (int64_t)par + 24 * t;  // S index of the trio's first sample
-                for (int k = 0; k < 12; ++k)
-                    R[k] = ((stream_mag<FMT>(a, s + 2 * k) ^ kBias) & 0xffffu) | ((stream_mag<FMT>(a, s + 2 * k + 1) ^ kBias) << 16);
+                for (int k = 0; k < 12; ++k) {
+                    const uint32_t lo = stream_mag_run<FMT>(a, s + 2 * k, zrun, zpos), hi = stream_mag_run<FMT>(a, s + 2 * k + 1, zrun, zpos);
+                    R[k] = ((lo ^ kBias) & 0xffffu) | ((hi ^ kBias) << 16);
+                }
             }
         };
         uint32_t c[15];
@@ -3000,7 +3068,7 @@ struct DcRaw {
 
 // phase 1: the state each tile would end in when started from zero
 template <int FMT>
-__global__ __launch_bounds__(kThreads) void k_dc_tile_sums(const void *iq, uint64_t n, double dc_a, double dc_b, double2 *tile_sums) {
+__global__ __launch_bounds__(kThreads) void k_dc_tile_sums(const void *iq, uint64_t n, double dc_a, double dc_b, double2 *tile_sums, float2 *local) {
     __shared__ double2 sh[kThreads];
     __shared__ float uc8f[256];
     if constexpr (FMT == kFmtUC8) {
@@ -3010,18 +3078,31 @@ __global__ __launch_bounds__(kThreads) void k_dc_tile_sums(const void *iq, uint6
     const uint64_t first = (uint64_t)blockIdx.x * kDcTile + (uint64_t)threadIdx.x * kDcPerThread;
     DcRaw<FMT> raw;
     raw.load(iq, first, n, (uintptr_t)iq % 16 == 0);
-    double zI = 0, zQ = 0;
+    double zI = 0, zQ = 0, midI = 0, midQ = 0;
 #pragma unroll
     for (int k = 0; k < kDcPerThread; ++k) {  // (samples beyond the end of the call only reach a sum that no later tile uses)
         float fI, fQ;
         raw.sample(k, uc8f, fI, fQ);
         zI = (double)fI * dc_a + zI * dc_b;
         zQ = (double)fQ * dc_a + zQ * dc_b;
+        if (k == 7) {
+            midI = zI;
+            midQ = zQ;
+        }
     }
-    double m16 = dc_b;
-    for (int k = 0; k < 4; ++k) m16 *= m16;  // dc_b^16
+    double m8 = dc_b;
+    for (int k = 0; k < 3; ++k) m8 *= m8;  // dc_b^8
+    const double m16 = m8 * m8;
     const DcScan v = dc_block_scan(make_double2(zI, zQ), m16, sh);
     if (threadIdx.x == kThreads - 1) tile_sums[blockIdx.x] = v.incl;
+    if (local) {
+        // the DC block inside the scan (dc_state_before_chunk): the state before each of the thread's two 8-sample chunks, had the
+        // tile started from zero; what the tile really starts with is added where the state is used
+        static_assert(kDcPerThread == 16, "two chunks per thread");
+        const float2 c0 = make_float2((float)v.excl.x, (float)v.excl.y);
+        const float2 c1 = make_float2((float)(v.excl.x * m8 + midI), (float)(v.excl.y * m8 + midQ));
+        ((float4 *)local)[(size_t)blockIdx.x * kThreads + threadIdx.x] = make_float4(c0.x, c0.y, c1.x, c1.y);
+    }
 }
 
 // phase 2: state at the start of every tile; state[0] = the carried-in state, state[ntiles] = the state to carry out.
@@ -3213,7 +3294,18 @@ hipError_t launch_scan(const BatchArgs &a, int grid, hipStream_t s) {
     const uint64_t need = (nstrips + kScanWaves - 1) / kScanWaves;
     if ((uint64_t)grid > need) grid = (int)need;
     return by_format(a.fmt, [&](auto F) {
-        auto kern = k_scan<decltype(F)::value>;
+        constexpr int f = decltype(F)::value;
+        if constexpr (f == kFmtSC16 || f == kFmtSC16Q11) {
+            if (a.dc_local) {  // the DC block inside the scan
+                auto kern = k_scan<f, true>;
+                hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanShared));
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanThreads), sizeof(ScanShared), s, a);
+                return hipGetLastError();
+            }
+        }
+        if (a.dc_local) return hipErrorInvalidValue;
+        auto kern = k_scan<f>;
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanShared));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanThreads), sizeof(ScanShared), s, a);
@@ -3651,12 +3743,90 @@ hipError_t launch_modeac(const BatchArgs &a, hipStream_t s) {
     });
 }
 
+void dc_coefficients(float *dc_a, float *dc_b) {
+    // convert.c:480-488: dc_b = (float)exp(-2 pi / sample_rate), dc_a = (float)(1.0 - dc_b)
+    *dc_b = (float)std::exp(-2.0 * 3.14159265358979323846 * 1.0 / 2400000.0);
+    *dc_a = (float)(1.0 - (double)*dc_b);
+}
+
+void dc_pow_table(double *out512) {
+    float dc_a, dc_b;
+    dc_coefficients(&dc_a, &dc_b);
+    double m8 = (double)dc_b;
+    for (int k = 0; k < 3; ++k) m8 *= m8;  // dc_b^8, as k_dc_tile_sums forms it
+    double p = 1.0;
+    for (int j = 0; j < 512; ++j, p *= m8) out512[j] = p;
+}
+
+namespace {
+template <int FMT>
+__global__ __launch_bounds__(kThreads) void k_dc_carry(const BatchArgs a, uint16_t *carry_out) {  // the batch's last 326 magnitudes
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < (uint32_t)kTrailing) carry_out[i] = (uint16_t)stream_mag<FMT>(a, (int64_t)a.n + (int64_t)i);
+}
+template <int FMT>
+__global__ __launch_bounds__(kThreads) void k_dc_materialize(const BatchArgs a, uint16_t *mag) {  // one thread per 8-sample chunk
+    const uint64_t c = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (8 * c >= a.n) return;
+    float2 z = make_float2(0.0f, 0.0f);
+    int64_t zpos = -1;
+    for (uint64_t i = 8 * c; i < 8 * c + 8 && i < a.n; ++i) mag[i] = (uint16_t)stream_mag_run<FMT>(a, (int64_t)i + (int64_t)kTrailing, z, zpos);
+}
+}  // namespace
+
+hipError_t launch_dc_carry(const BatchArgs &a, uint16_t *carry_out, hipStream_t s) {
+    return by_format(a.fmt, [&](auto F) {
+        constexpr int f = decltype(F)::value;
+        if constexpr (f == kFmtSC16 || f == kFmtSC16Q11) {
+            hipLaunchKernelGGL(k_dc_carry<f>, dim3((kTrailing + kThreads - 1) / kThreads), dim3(kThreads), 0, s, a, carry_out);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    });
+}
+
+hipError_t launch_dc_materialize(const BatchArgs &a, uint16_t *mag, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    return by_format(a.fmt, [&](auto F) {
+        constexpr int f = decltype(F)::value;
+        if constexpr (f == kFmtSC16 || f == kFmtSC16Q11) {
+            hipLaunchKernelGGL(k_dc_materialize<f>, dim3((unsigned)((a.n / 8 + kThreads) / kThreads)), dim3(kThreads), 0, s, a, mag);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    });
+}
+
+hipError_t launch_dc_states(int fmt, const void *iq, uint64_t n, double2 *tile_sums, double2 *tile_start, float2 *local, double2 *z_state, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    float dc_a, dc_b;
+    dc_coefficients(&dc_a, &dc_b);
+    const uint32_t ntiles = (uint32_t)((n + kDcTile - 1) / kDcTile);
+    return by_format(fmt, [&](auto F) {
+        constexpr int f = decltype(F)::value;
+        if constexpr (f == kFmtSC16 || f == kFmtSC16Q11) {
+            hipLaunchKernelGGL(k_dc_tile_sums<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, n, (double)dc_a, (double)dc_b, tile_sums, local);
+            const uint32_t nchunks = (ntiles + kDcChunkTiles - 1) / kDcChunkTiles;
+            hipLaunchKernelGGL(k_dc_scan_local, dim3(nchunks), dim3(kDcChunkTiles), 0, s, tile_sums, tile_start, ntiles, (double)dc_b);
+            hipLaunchKernelGGL(k_dc_scan_finish, dim3(nchunks), dim3(kDcChunkTiles), 0, s, tile_sums, tile_start, ntiles, z_state, (double)dc_b);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            // the state after the batch's last sample, for the next batch (a batch that is not a whole number of tiles ends its stream)
+            if (n % kDcTile == 0) e = hipMemcpyAsync(z_state, tile_start + ntiles, sizeof(double2), hipMemcpyDeviceToDevice, s);
+            return e;
+        } else {
+            return hipErrorInvalidValue;
+        }
+    });
+}
+
 hipError_t launch_convert_dc(int fmt, const void *iq, uint16_t *mag, uint64_t n, double2 *tile_sums, double2 *tile_start, double2 *z_state, double *block_means,
                              hipStream_t s) {
     if (n == 0) return hipSuccess;
-    // convert.c:480-488: dc_b = (float)exp(-2 pi / sample_rate), dc_a = (float)(1.0 - dc_b)
-    const float dc_b = (float)std::exp(-2.0 * 3.14159265358979323846 * 1.0 / 2400000.0);
-    const float dc_a = (float)(1.0 - (double)dc_b);
+    float dc_a, dc_b;
+    dc_coefficients(&dc_a, &dc_b);
     const uint32_t ntiles = (uint32_t)((n + kDcTile - 1) / kDcTile), nblocks = (uint32_t)((n + kBlock - 1) / kBlock);
     return by_format(fmt, [&](auto F) {
         constexpr int f = decltype(F)::value;
@@ -3666,7 +3836,7 @@ hipError_t launch_convert_dc(int fmt, const void *iq, uint16_t *mag, uint64_t n,
             hipError_t e = hipSuccess;
             if (block_means) e = hipMemsetAsync(block_means, 0, (size_t)nblocks * 2 * sizeof(double), s);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_dc_tile_sums<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, n, (double)dc_a, (double)dc_b, tile_sums);
+            hipLaunchKernelGGL(k_dc_tile_sums<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, n, (double)dc_a, (double)dc_b, tile_sums, (float2 *)nullptr);
             const uint32_t nchunks = (ntiles + kDcChunkTiles - 1) / kDcChunkTiles;
             hipLaunchKernelGGL(k_dc_scan_local, dim3(nchunks), dim3(kDcChunkTiles), 0, s, tile_sums, tile_start, ntiles, (double)dc_b);
             hipLaunchKernelGGL(k_dc_scan_finish, dim3(nchunks), dim3(kDcChunkTiles), 0, s, tile_sums, tile_start, ntiles, z_state, (double)dc_b);

@@ -113,6 +113,14 @@ struct BatchArgs {
     int debug_flags;         // ablation only (RSB_ABL): 1 skip classify, 2 skip slicing loads, 4 skip reductions
     int stage_limit;         // debug/ablation only (RSB_STAGE_LIMIT): stop the scan kernel after stage k
     uint32_t block_len;      // samples per demodulator call (mag_buf.length of a full buffer): 131072 unless the source builds other buffers
+    // --dcfilter inside the scan (SC16 / SC16Q11; DESIGN.md "DC block, fused"): the filter state before every 8-sample chunk of iq is
+    // (float)(dc_local[chunk] + dc_tile_start[chunk / 512] * dc_pow[chunk % 512]); the samples of a chunk then go through the
+    // reference's float recurrence (convert.c:137-140) from there.  Null dc_local: no DC filter in the scan.
+    const float2 *dc_local;        // per chunk: the state before it had the chunk's 4096-sample tile started from zero
+    const double2 *dc_tile_start;  // per tile: the state at its start
+    const double *dc_pow;          // dc_b^(8 j), j < 512
+    float dc_a, dc_b;
+    int carry_is_mag;              // the carry holds 326 magnitudes (u16), not samples of fmt
     void *carry_out;         // rsb_submit_many's one launch: where the batch's last 326 samples go (the next batch's carry), or null
     uint64_t *wave_times;    // debug only (RSB_WAVE_TIMES): per scan wavefront {start, end (100 MHz ticks), XCC id << 32 | HW_ID, strips taken}
 };
@@ -250,6 +258,15 @@ hipError_t launch_means_average(const double *sub_means, uint32_t nsub, uint32_t
 // samples (+1); z_state is the carried DC state (in: before sample 0, out: after sample n-1); block_means (optional) receives
 // the mean level / mean power of every 131072-sample block of the call
 constexpr int kDcTileSamples = 4096;
+// The fused form's share of launch_convert_dc: tile sums (one read of the IQ), the scan over them, and -- new -- the per-chunk local
+// states; no magnitudes are written.  z_state: carried in, and out when n is a whole number of tiles.
+hipError_t launch_dc_states(int fmt, const void *iq, uint64_t n, double2 *tile_sums, double2 *tile_start, float2 *local, double2 *z_state, hipStream_t s);
+// dc_b^(8 j), j < 512, as the kernels use it (512 doubles on the host)
+void dc_pow_table(double *out512);
+void dc_coefficients(float *dc_a, float *dc_b);
+// the last 326 magnitudes of a fused-DC batch -> carry_out (u16); the batch's magnitudes [0, n) -> mag (tests: rsb_get_batch_magnitudes)
+hipError_t launch_dc_carry(const BatchArgs &a, uint16_t *carry_out, hipStream_t s);
+hipError_t launch_dc_materialize(const BatchArgs &a, uint16_t *mag, hipStream_t s);
 hipError_t launch_convert_dc(int fmt, const void *iq, uint16_t *mag, uint64_t n, double2 *tile_sums, double2 *tile_start, double2 *z_state, double *block_means,
                              hipStream_t s);
 hipError_t launch_convert(int fmt, const void *iq, uint16_t *mag, uint64_t n, const uint16_t *lut, uint64_t *sums, hipStream_t s);

@@ -90,6 +90,51 @@ def test_dcfilter_stream(name, built):
         assert abs(a["signal"] - b["signal"]) <= rel * abs(a["signal"]) + 1e-12
 
 
+@pytest.mark.parametrize("name", ["sc16_dc", "sc16_dc_highsnr"])
+def test_dcfilter_inside_the_scan_in_batches(name, built):
+    """--dcfilter on a 16-bit format without Mode A/C runs with the DC block inside the kernels (no magnitude buffer: a pass over the IQ
+    leaves the filter's state per 8-sample chunk, every kernel takes its samples through convert.c:137-140 from there).  In batches of
+    two blocks: the filter state and the 326-sample overlap (kept as magnitudes) cross the batch boundaries.  The magnitudes the
+    library reports for each batch (made on request by the same routine) are within 1 LSB of the exact recurrence over the WHOLE
+    recording, the messages are bit-exact against the oracle run on those magnitudes, and two batches in flight give the same lists."""
+    import torch
+    from scipy.signal import lfilter
+
+    sc, kw = SCENARIOS[name]
+    iq = generate(sc)
+    n, nb = sc.n_samples, 2 * 131072
+    dev = torch.from_numpy(np.ascontiguousarray(iq)).cuda()
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=False, dc_filter=True, max_batch_samples=nb)
+    parts, mags = [], []
+    for a in range(0, n, nb):
+        k = min(nb, n - a)
+        ch.submit(dev.data_ptr() + 4 * a, k)
+        parts.append(ch.collect(cap=1 << 14).copy())
+        mags.append(ch.batch_magnitudes(k)[0])
+    ch.close()
+    mag = np.concatenate(mags)
+    got = np.concatenate(parts).view(REC_DTYPE)
+    x = (iq.reshape(n, 2).astype(np.float32) / np.float32(32768.0)).astype(np.float64)
+    dc_b = float(np.float32(np.exp(-2.0 * np.pi / 2.4e6)))
+    dc_a = float(np.float32(1.0 - dc_b))
+    y = x - lfilter([dc_a], [1.0, -dc_b], x, axis=0)
+    exact = np.floor(np.sqrt(np.minimum(1.0, (y * y).sum(axis=1))) * 65535.0 + 0.5).astype(np.int64)
+    assert np.abs(mag.astype(np.int64) - exact).max() <= 1
+    on_mags = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=False).run_mag_stream(mag, None)
+    assert got.size > 100 and first_mismatch(on_mags, got) is None
+    # two batches in flight (the filter states of a batch live in its slot)
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=False, dc_filter=True, max_batch_samples=nb)
+    cuts = list(range(0, n, nb)) + [n]
+    again = []
+    ch.submit(dev.data_ptr(), cuts[1])
+    for i in range(1, len(cuts)):
+        if i + 1 < len(cuts):
+            ch.submit(dev.data_ptr() + 4 * cuts[i], cuts[i + 1] - cuts[i])
+        again.append(ch.collect(cap=1 << 14).copy())
+    ch.close()
+    assert np.concatenate(again).tobytes() == np.concatenate(parts).tobytes()
+
+
 @REPLAY
 @pytest.mark.parametrize("batch_blocks", [0, 2])
 @pytest.mark.parametrize("name", list(TABLE_SCENARIOS))
