@@ -184,6 +184,7 @@ int reset_device(rsb_ctx *c) {
     HIP_TRY(c, hipMemsetAsync(c->d_bitmap, 0, (1u << 24) / 8, c->replay_stream));
     // icaoFilterTest(0) is true on an empty slot (icao_filter.c:101-107): address 0 is always a "member"
     HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_bitmap, 1, 1, c->replay_stream));
+    if (c->d_dc_state) HIP_TRY(c, hipMemsetAsync(c->d_dc_state, 0, sizeof(double2), c->replay_stream));  // a new recording: the DC block starts from zero, as init_converter leaves it
     HIP_TRY(c, hipEventRecord(c->reset_done, c->replay_stream));
     c->reset_pending = true;
     c->filter_dirty = true;
@@ -1543,7 +1544,7 @@ static bool one_chain_possible(rsb_ctx *const *ctx, size_t nch) {
     const rsb_ctx *c0 = ctx[0];
     for (size_t i = 0; i < nch; ++i) {
         rsb_ctx *c = ctx[i];
-        if (c->cfg.device != c0->cfg.device || c->cfg.input_format != c0->cfg.input_format || !c->any_pending()) return false;
+        if (c->cfg.device != c0->cfg.device || c->cfg.input_format != c0->cfg.input_format || !c->any_pending() || c->cfg.dc_filter) return false;
         const rsb_slot &b = c->collect_slot();
         if (!b.pending || b.chain_enqueued || b.pruned || !chain_needs_no_host(c, b) || b.pending_args.fmt != ctx[0]->collect_slot().pending_args.fmt) return false;
         for (size_t k = 0; k < i; ++k)

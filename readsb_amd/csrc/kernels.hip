@@ -131,8 +131,13 @@ __device__ __forceinline__ uint32_t dc_sample(uint32_t w, float dc_a, float dc_b
     return float_mag(xI, xQ);
 }
 template <int FMT>
+__device__ __forceinline__ uint4 dc_chunk_from(const BatchArgs &a, const uint4 x0, const uint4 x1, float2 z);
+template <int FMT>
 __device__ __forceinline__ uint4 dc_chunk(const BatchArgs &a, const uint4 x0, const uint4 x1, uint64_t chunk) {  // -> 8 biased magnitudes
-    float2 z = dc_state_before_chunk(a, chunk);
+    return dc_chunk_from<FMT>(a, x0, x1, dc_state_before_chunk(a, chunk));
+}
+template <int FMT>
+__device__ __forceinline__ uint4 dc_chunk_from(const BatchArgs &a, const uint4 x0, const uint4 x1, float2 z) {
     const uint32_t W[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
     uint32_t m[8];
 #pragma unroll
@@ -2007,8 +2012,9 @@ struct __attribute__((aligned(16))) EmitShared {
 
 typedef uint4 __attribute__((aligned(4))) uint4_a4;
 
-template <int FMT>
+template <int FMT, bool DC = false>
 __device__ __forceinline__ void replay_emit_body(const BatchArgs &a, const ReplayArgs &r) {
+    static_assert(!DC || FMT == kFmtSC16 || FMT == kFmtSC16Q11, "the DC block inside the kernels: 16-bit formats");
     extern __shared__ __attribute__((aligned(16))) unsigned char emit_lds[];  // 66 KB: over the static limit
     EmitShared &sh = *reinterpret_cast<EmitShared *>(emit_lds);
     constexpr uint32_t kT = 64 * kEmitWaves;
@@ -2082,23 +2088,88 @@ __device__ __forceinline__ void replay_emit_body(const BatchArgs &a, const Repla
         const int64_t e0 = (int64_t)g + 19 - (int64_t)kTrailing;  // index into iq of the first data sample (may be < 0: the overlap)
         const uint32_t par = (uint32_t)e0 & 1u;
         const int64_t sd = e0 - (int64_t)par;
-        const bool direct = a.iq_aligned && sd >= 0 && sd + 24 * ntrios <= (int64_t)a.n && !a.dc_local;  // (DC block: through the filter, sample by sample)
+        // With the DC block (DC: the kernel's own variant) the window is fetched from the 8-sample chunk that holds its first sample:
+        // a trio is then three whole chunks of the filter's states plus the first chunk of the next trio, and the lane picks its 12
+        // rows out of those 16 by its offset into the chunk (0..3 rows).  Rows 140.. of the window are never used, so the last
+        // trio does without a successor.  (A batch with the filter in a kernel built without DC takes the sample-by-sample path.)
+        const int64_t sda = DC ? (sd & ~(int64_t)7) : sd;
+        const bool direct = a.iq_aligned && sd >= 0 && sda + 24 * ntrios + (DC ? 8 : 0) <= (int64_t)a.n && (DC || !a.dc_local);
         float2 zrun = make_float2(0.0f, 0.0f);
         int64_t zpos = -1;
+        [[maybe_unused]] uint32_t dc_carry[4] = {0, 0, 0, 0};
         // (lanes that cannot read their window directly read the head of the UC8 table instead -- always there, 128 KB -- and
         // ignore it: behind a branch the compiler cannot count the loads in flight and waits for ALL of them at every use,
         // refills included, so nothing of the prefetch overlapped anything)
-        const uint4_a4 *src = direct ? (const uint4_a4 *)((const uint8_t *)a.iq + kBps * sd) : (const uint4_a4 *)a.tab.uc8_lut;
-        constexpr int kFlight = RSB_EMIT_FLIGHT;  // trios in flight (both trio counts, 12 and 8, are multiples of it)
+        const uint4_a4 *src = direct ? (const uint4_a4 *)((const uint8_t *)a.iq + kBps * sda) : (const uint4_a4 *)a.tab.uc8_lut;
+        constexpr int kFlight = DC ? 2 : RSB_EMIT_FLIGHT;  // trios in flight (both trio counts, 12 and 8, are multiples of it; DC: four would spill)
         uint4 raw[kFlight][3][kRawVecs];
+        // DC: the chunks' local filter states travel with the raw samples; the tile's starting state (the window crosses into the next
+        // tile at most once) and the power of dc_b are kept running -- dc_pow[j + 1] = dc_pow[j] * dc_pow[1] is how the table was made
+        [[maybe_unused]] float2 lz[DC ? kFlight : 1][3];
+        [[maybe_unused]] const float2 *lsrc = a.dc_local;
+        [[maybe_unused]] double2 z0a = make_double2(0, 0), z0b = make_double2(0, 0);
+        [[maybe_unused]] double pj = 1.0, m8 = 1.0;
+        [[maybe_unused]] uint32_t jj = 0;
+        if constexpr (DC) {
+            if (direct) {
+                const uint64_t cf = (uint64_t)sda >> 3;
+                lsrc = a.dc_local + cf;
+                z0a = a.dc_tile_start[cf >> 9];
+                z0b = a.dc_tile_start[(cf >> 9) + 1];
+                jj = (uint32_t)cf & 511u;
+                pj = a.dc_pow[jj];
+            }
+            m8 = a.dc_pow[1];
+        }
+        auto next_state = [&](const float2 l) -> float2 {  // the state before the next chunk of the window, in ascending order
+            const float2 z = make_float2((float)((double)l.x + z0a.x * pj), (float)((double)l.y + z0a.y * pj));
+            pj *= m8;
+            if (++jj == 512u) {
+                jj = 0;
+                pj = 1.0;
+                z0a = z0b;
+            }
+            return z;
+        };
         auto issue = [&](int slot, int t) {
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int v = 0; v < kRawVecs; ++v) raw[slot][k][v] = src[kRawVecs * (3 * t + k) + v];
+            if constexpr (DC) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) lz[slot][k] = lsrc[3 * t + k];
+            }
         };
         auto rows_of = [&](int slot, int t, uint32_t (&R)[12]) {  // 24 samples from row 12 t on -> 12 rows of biased magnitude pairs
-            if (direct) {
+            if (DC && direct) {
+                if constexpr (DC) {
+                    uint32_t E[16];
+                    if (t == 0) {  // (every later trio has its first chunk from the trio before: dc_carry)
+                        const uint4 o = dc_chunk_from<FMT>(a, raw[slot][0][0], raw[slot][0][kRawVecs - 1], next_state(lz[slot][0]));
+                        dc_carry[0] = o.x;
+                        dc_carry[1] = o.y;
+                        dc_carry[2] = o.z;
+                        dc_carry[3] = o.w;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) E[k] = dc_carry[k];
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) {
+                        const int sl = k < 3 ? slot : (slot + 1) % kFlight, kk = k < 3 ? k : 0;  // the trio after this one is in the next slot
+                        const uint4 o = dc_chunk_from<FMT>(a, raw[sl][kk][0], raw[sl][kk][kRawVecs - 1], next_state(lz[sl][kk]));
+                        E[4 * k] = o.x;
+                        E[4 * k + 1] = o.y;
+                        E[4 * k + 2] = o.z;
+                        E[4 * k + 3] = o.w;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dc_carry[k] = E[12 + k];
+                    const uint32_t shift = ((uint32_t)sd & 7u) >> 1;
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) R[k] = shift == 0 ? E[k] : (shift == 1 ? E[k + 1] : (shift == 2 ? E[k + 2] : E[k + 3]));
+                }
+            } else if (direct) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     uint4 o;
@@ -2155,7 +2226,7 @@ __device__ __forceinline__ void replay_emit_body(const BatchArgs &a, const Repla
                 // fetch (a trio at a time, the next piece of a line came a few hundred instructions of seven other wavefronts later)
                 // (the refill is unconditional -- past the frame's end it reads the last trio again and nobody uses it: after a
                 // conditional load the compiler no longer knows how many loads are in flight and waits for all of them)
-                if (RSB_EMIT_BURST) {
+                if (RSB_EMIT_BURST && !DC) {  // (DC, two in flight: the slot after this one must hold the next trio already)
                     if (slot & 1) {
                         issue(slot - 1, min(t + kFlight - 1, ntrios - 1));
                         issue(slot, min(t + kFlight, ntrios - 1));
@@ -2308,8 +2379,8 @@ __global__ __launch_bounds__(kThreads) void k_replay_table_min(const ReplayArgs 
 __global__ __launch_bounds__(kThreads) void k_replay_compare(const ReplayArgs r, uint32_t *changed) { replay_compare_body(r, changed); }
 __global__ __launch_bounds__(kThreads) void k_replay_list(const ReplayArgs r, uint32_t *counters) { replay_list_body(r, counters); }
 __global__ __launch_bounds__(kThreads) void k_replay_fold(const ReplayArgs r) { replay_fold_body(r); }
-template <int FMT>
-__global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs a, const ReplayArgs r) { replay_emit_body<FMT>(a, r); }
+template <int FMT, bool DC = false>
+__global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs a, const ReplayArgs r) { replay_emit_body<FMT, DC>(a, r); }
 
 // (the summary words start at zero: this kernel stands where launch_prune_ordered has its memset)
 __global__ __launch_bounds__(kThreads) void k_prune_summary_clear_many(const ChainArgs *__restrict__ m) {
@@ -3462,13 +3533,24 @@ hipError_t launch_replay_fold(const ReplayArgs &r, hipStream_t s) {
 hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream_t s) {
     if (r.n_items == 0) return hipSuccess;
     return by_format(a.fmt, [&](auto F) {
-        auto kern = k_replay_emit<decltype(F)::value>;
-        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmitShared));
-        if (e != hipSuccess) return e;
+        constexpr int f = decltype(F)::value;
         // r.n_items bounds the KEPT ITEMS; messages are a third of them or fewer, and every workgroup pays a 32 KB table copy: a
         // grid for a quarter of the bound (the kernel strides over whatever the count turns out to be)
         const unsigned g = (r.n_items / 4 + 64 * kEmitWaves - 1) / (64 * kEmitWaves);
-        hipLaunchKernelGGL(kern, dim3(g < 1 ? 1 : (g > (unsigned)kEmitGroups ? (unsigned)kEmitGroups : g)), dim3(64 * kEmitWaves), sizeof(EmitShared), s, a, r);
+        const dim3 grid(g < 1 ? 1 : (g > (unsigned)kEmitGroups ? (unsigned)kEmitGroups : g));
+        if constexpr (f == kFmtSC16 || f == kFmtSC16Q11) {
+            if (a.dc_local) {  // the DC block inside the kernel
+                auto kern = k_replay_emit<f, true>;
+                const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmitShared));
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, grid, dim3(64 * kEmitWaves), sizeof(EmitShared), s, a, r);
+                return hipGetLastError();
+            }
+        }
+        auto kern = k_replay_emit<f>;
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmitShared));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * kEmitWaves), sizeof(EmitShared), s, a, r);
         return hipGetLastError();
     });
 }
