@@ -3249,7 +3249,7 @@ static_assert(0xfffff000ull / kDcTile / kDcChunkTiles < (unsigned long long)kDcC
 // phase 3: magnitudes.  sums (optional): per 131072-sample block of this call, sum(mag) and sum(magsq) as doubles.
 template <int FMT>
 __global__ __launch_bounds__(kThreads) void k_convert_dc(const void *iq, uint16_t *mag, uint64_t n, float dc_a, float dc_b, const double2 *tile_start, double *sums,
-                                                         double2 *z_out, int abl) {
+                                                         double2 *tile_part, double2 *z_out, int abl) {
     __shared__ double2 sh[kThreads];
     __shared__ uint4 stage[kDcTile / 8];
     __shared__ float uc8f[256];
@@ -3317,26 +3317,41 @@ __global__ __launch_bounds__(kThreads) void k_convert_dc(const void *iq, uint16_
         o[threadIdx.x + kThreads] = stage[threadIdx.x + kThreads];
     }
     if (sums) {
+        // the tile's two sums in a fixed order (lanes by halving, then the four wavefronts in turn): k_dc_means adds the tiles of a
+        // block in ascending order, so a block's means are the same bits on every run (atomics here added in whatever order the
+        // wavefronts arrived)
         for (int off = 32; off > 0; off >>= 1) {
             sl += __shfl_down(sl, off, 64);
             sp += __shfl_down(sp, off, 64);
         }
-        if ((threadIdx.x & 63) == 0 && first < n) {
-            const uint64_t blk = first / kBlock;
-            atomicAdd(&sums[2 * blk], sl);
-            atomicAdd(&sums[2 * blk + 1], sp);
+        __syncthreads();  // (sh: the scan above is done with it)
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = make_double2(sl, sp);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double2 t = sh[0];
+            for (int w = 1; w < kThreads / 64; ++w) {
+                t.x += sh[w].x;
+                t.y += sh[w].y;
+            }
+            tile_part[blockIdx.x] = t;
         }
     }
 }
 
 // block sums -> the converter's per-call means (float / unsigned division widened afterwards, convert.c:155-161)
-__global__ void k_dc_means(double *sums, uint64_t n, uint32_t nblocks) {
+__global__ void k_dc_means(double *sums, const double2 *tile_part, uint32_t ntiles, uint64_t n, uint32_t nblocks) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
     const uint64_t start = (uint64_t)b * kBlock;
     const double len = (double)((n - start < (uint64_t)kBlock) ? (n - start) : (uint64_t)kBlock);
-    sums[2 * b] /= len;
-    sums[2 * b + 1] /= len;
+    constexpr uint32_t per = kBlock / kDcTile;  // 32 tiles per block
+    double sl = 0, sp = 0;
+    for (uint32_t t = b * per; t < (b + 1) * per && t < ntiles; ++t) {
+        sl += tile_part[t].x;
+        sp += tile_part[t].y;
+    }
+    sums[2 * b] = sl / len;
+    sums[2 * b + 1] = sp / len;
 }
 
 template <typename F>
@@ -3915,16 +3930,14 @@ hipError_t launch_convert_dc(int fmt, const void *iq, uint16_t *mag, uint64_t n,
         if constexpr (f == kFmtMag16) {
             return hipErrorInvalidValue;
         } else {
-            hipError_t e = hipSuccess;
-            if (block_means) e = hipMemsetAsync(block_means, 0, (size_t)nblocks * 2 * sizeof(double), s);
-            if (e != hipSuccess) return e;
             hipLaunchKernelGGL(k_dc_tile_sums<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, n, (double)dc_a, (double)dc_b, tile_sums, (float2 *)nullptr);
             const uint32_t nchunks = (ntiles + kDcChunkTiles - 1) / kDcChunkTiles;
             hipLaunchKernelGGL(k_dc_scan_local, dim3(nchunks), dim3(kDcChunkTiles), 0, s, tile_sums, tile_start, ntiles, (double)dc_b);
             hipLaunchKernelGGL(k_dc_scan_finish, dim3(nchunks), dim3(kDcChunkTiles), 0, s, tile_sums, tile_start, ntiles, z_state, (double)dc_b);
             static const int abl = std::getenv("RSB_DC_ABL") ? std::atoi(std::getenv("RSB_DC_ABL")) : 0;  // ablation timing only
-            hipLaunchKernelGGL(k_convert_dc<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, mag, n, dc_a, dc_b, tile_start, block_means, z_state, abl);
-            if (block_means) hipLaunchKernelGGL(k_dc_means, dim3((nblocks + 255) / 256), dim3(256), 0, s, block_means, n, nblocks);
+            // (tile_sums is free again: the scan over the tiles has consumed it -- the tiles' partial sums of mag and mag^2 go there)
+            hipLaunchKernelGGL(k_convert_dc<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, mag, n, dc_a, dc_b, tile_start, block_means, tile_sums, z_state, abl);
+            if (block_means) hipLaunchKernelGGL(k_dc_means, dim3((nblocks + 255) / 256), dim3(256), 0, s, block_means, (const double2 *)tile_sums, ntiles, n, nblocks);
             return hipGetLastError();
         }
     });

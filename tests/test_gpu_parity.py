@@ -90,6 +90,19 @@ def test_dcfilter_stream(name, built):
         assert abs(a["signal"] - b["signal"]) <= rel * abs(a["signal"]) + 1e-12
 
 
+def test_dcfilter_block_means_are_the_same_bits_every_run(built):
+    """the DC converter's per-block means (demodulate2400AC's noise level): tiles summed in a fixed order, not by atomics"""
+    sc, kw = SCENARIOS["sc16q11_dc_ac"]
+    iq = generate(sc)
+    runs = []
+    for _ in range(3):
+        ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=True, dc_filter=True, max_batch_samples=1 << 22)
+        ch.process_host(iq)
+        runs.append(ch.batch_magnitudes(sc.n_samples, want_means=True)[1].tobytes())
+        ch.close()
+    assert runs[0] == runs[1] == runs[2] and np.frombuffer(runs[0], dtype=np.float64).min() > 0
+
+
 @pytest.mark.parametrize("name", ["sc16_dc", "sc16_dc_highsnr"])
 def test_dcfilter_inside_the_scan_in_batches(name, built):
     """--dcfilter on a 16-bit format without Mode A/C runs with the DC block inside the kernels (no magnitude buffer: a pass over the IQ
