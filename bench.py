@@ -233,7 +233,7 @@ def main() -> int:
     # the other BASELINE.json configurations (the default line stays configs[1]); parity for each is covered in tests/
     ap.add_argument("--format", choices=("UC8", "SC16", "SC16Q11"), default="UC8", help="configs[2]: 4-byte samples (bladeRF / Pluto)")
     ap.add_argument("--submit-ahead", type=int, default=-1, choices=(-1, 0, 1),
-                    help="two steps in flight: submit step k + 1 before waiting for step k's chain (default: with --dcfilter on a 16-bit format, "
+                    help="two steps in flight: submit step k + 1 before waiting for step k's chain (default: with --dcfilter, "
                          "where the pass that leaves the filter's states -- bound by HBM -- then runs beside step k's prune / replay / emit)")
     ap.add_argument("--dcfilter", action="store_true", help="configs[2]: the DC-block IIR as a chunked scan")
     ap.add_argument("--modeac", action="store_true", help="configs[4]: also demodulate2400AC")
@@ -296,9 +296,9 @@ def main() -> int:
     bs = -(-nc // nb) // 131072 * 131072 or nc
     cuts = list(range(0, nc, bs)) + [nc]
     # two steps in flight: two receiver channels take the steps in turn (one channel, one batch per step, records out)
-    # --dcfilter: on the 16-bit formats without Mode A/C the kernels filter for themselves (no magnitude buffer, batches overlap as without
-    # the filter); UC8 and Mode A/C contexts keep the converter and its one magnitude buffer: one step at a time
-    dc_fused = args.dcfilter and args.format != "UC8" and not args.modeac and not os.environ.get("RSB_DC_UNFUSED")
+    # --dcfilter: without Mode A/C the kernels filter for themselves (no magnitude buffer, batches overlap as without the filter); Mode A/C
+    # contexts keep the converter and its one magnitude buffer: one step at a time
+    dc_fused = args.dcfilter and not args.modeac and not os.environ.get("RSB_DC_UNFUSED")
     if args.submit_ahead < 0:
         args.submit_ahead = 1 if dc_fused else 0
     overlap = args.steps_in_flight == 2 and C == 1 and nb == 1 and args.output == "records" and (not args.dcfilter or dc_fused)

@@ -101,10 +101,9 @@ int setup_device(rsb_ctx *c) {
     }
     // --dcfilter (and the SC16Q11 table converter) keeps one magnitude buffer, which the replay of a batch still reads: one batch in flight there
     c->q11_table_bits = (int)RSB_FLAG_SC16Q11_TABLE_BITS_OF(c->cfg.flags);
-    // ... unless the kernels filter for themselves (16-bit formats, Mode S only, no exact statistics: those two take the converter's
+    // ... unless the kernels filter for themselves (Mode S only, no exact statistics: those two take the converter's
     // block means): then a batch's filter states live in its slot and batches overlap as without the filter
-    c->dc_fused = c->cfg.dc_filter && !c->q11_table_bits && (c->cfg.input_format == RSB_SC16 || c->cfg.input_format == RSB_SC16Q11) && !c->run_ac &&
-                  !c->exact_stats && !std::getenv("RSB_DC_UNFUSED");
+    c->dc_fused = c->cfg.dc_filter && !c->q11_table_bits && !c->run_ac && !c->exact_stats && !std::getenv("RSB_DC_UNFUSED");
     c->nslots = c->dc_fused ? 2 : ((c->cfg.dc_filter || c->q11_table_bits) ? 1 : rsb_ctx::kMaxSlots);
     for (int k = 0; k < c->nslots; ++k) {
         rsb_slot &b = c->slots[k];
@@ -898,7 +897,7 @@ int rsb_submit(rsb_ctx *c, const void *iq_dev, uint64_t nsamples, void *stream) 
         c->reset_pending = false;
     }
     if (c->dc_fused) {
-        // --dcfilter, 16-bit formats: one pass over the IQ leaves the filter's state before every 8-sample chunk; the scan (and
+        // --dcfilter, Mode S only: one pass over the IQ leaves the filter's state before every 8-sample chunk; the scan (and
         // whatever else needs a magnitude) takes the samples through the filter itself.  No magnitude touches memory.
         HIP_TRY(c, launch_dc_states(c->cfg.input_format, iq_dev, nsamples, c->d_dc_tile_sums, b.d_dc_tile_start, b.d_dc_local, c->d_dc_state, s));
         BatchArgs a = c->batch_args(b, iq_dev, nsamples, c->cfg.input_format);

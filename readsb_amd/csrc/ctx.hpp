@@ -136,7 +136,7 @@ struct rsb_ctx {
     int q11_table_bits = 0;  // RSB_FLAG_SC16Q11_TABLE: the converter of a reference built with -DSC16Q11_TABLE_BITS (0 = the float one)
     double2 *d_dc_tile_sums = nullptr, *d_dc_tile_start = nullptr, *d_dc_state = nullptr;
     size_t dc_tiles_cap = 0;
-    bool dc_fused = false;            // --dcfilter without a magnitude buffer: SC16 / SC16Q11, Mode S only (the scan, the candidate and the record kernels filter for themselves)
+    bool dc_fused = false;            // --dcfilter without a magnitude buffer: Mode S only (the scan, the candidate and the record kernels filter for themselves)
     double *d_dc_pow = nullptr;
     uint16_t *d_dc_mags = nullptr;    // rsb_get_batch_magnitudes on such a context: the last batch's magnitudes, made on request
     size_t dc_mags_cap = 0;

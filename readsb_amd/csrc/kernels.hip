@@ -119,11 +119,27 @@ __device__ __forceinline__ float2 dc_state_before_chunk(const BatchArgs &a, uint
     const double p = a.dc_pow[chunk & 511u];
     return make_float2((float)((double)l.x + z0.x * p), (float)((double)l.y + z0.y * p));
 }
-// one SC16 / SC16Q11 sample through the filter (state z) -> its magnitude
+// convert.c:131-132, ((float)v - 127.5f) / 127.5f, without the division: the product with the rounded reciprocal and one
+// correction step give the correctly rounded quotient for all 256 values of v (checked exhaustively: tests/test_uc8_scaling.py)
+__device__ __forceinline__ float uc8_scaled(uint32_t v) {
+    constexpr float c = 1.0f / 127.5f;
+    const float n = (float)v - 127.5f;
+    float q = n * c;
+    const float r = __builtin_fmaf(-q, 127.5f, n);
+    return __builtin_fmaf(r, c, q);
+}
+// one sample (SC16 / SC16Q11: a dword, UC8: its two bytes) through the filter (state z) -> its magnitude
 template <int FMT>
 __device__ __forceinline__ uint32_t dc_sample(uint32_t w, float dc_a, float dc_b, float2 &z) {
-    constexpr float scale = (FMT == kFmtSC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);  // exact: a power of two
-    float xI = (float)(short)(w & 0xffffu) * scale, xQ = (float)(short)(w >> 16) * scale;
+    float xI, xQ;
+    if constexpr (FMT == kFmtUC8) {
+        xI = uc8_scaled(w & 0xffu);
+        xQ = uc8_scaled((w >> 8) & 0xffu);
+    } else {
+        constexpr float scale = (FMT == kFmtSC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);  // exact: a power of two
+        xI = (float)(short)(w & 0xffffu) * scale;
+        xQ = (float)(short)(w >> 16) * scale;
+    }
     z.x = xI * dc_a + z.x * dc_b;  // convert.c:137-140
     z.y = xQ * dc_a + z.y * dc_b;
     xI -= z.x;
@@ -138,7 +154,12 @@ __device__ __forceinline__ uint4 dc_chunk(const BatchArgs &a, const uint4 x0, co
 }
 template <int FMT>
 __device__ __forceinline__ uint4 dc_chunk_from(const BatchArgs &a, const uint4 x0, const uint4 x1, float2 z) {
-    const uint32_t W[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    uint32_t W[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    if constexpr (FMT == kFmtUC8) {  // 8 samples in x0 alone
+        const uint32_t X[4] = {x0.x, x0.y, x0.z, x0.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) W[k] = (X[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+    }
     uint32_t m[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) m[k] = dc_sample<FMT>(W[k], a.dc_a, a.dc_b, z) ^ 0x8000u;  // (the LDS arrays' bias, kBias below)
@@ -147,7 +168,9 @@ __device__ __forceinline__ uint4 dc_chunk_from(const BatchArgs &a, const uint4 x
 
 // S[s] of the batch stream S = carry(326) ++ iq(n); zero outside.  The *_run form keeps the DC filter's state between calls for
 // ascending s (zpos = the iq index the state z is valid for; -1: none): one step per sample instead of a walk from the chunk's start.
-template <int FMT>
+// (MAYBE_DC = false: for kernels that are never launched on a batch with the filter -- the scan has a variant of its own for those,
+// and the plain one keeps its register allocation)
+template <int FMT, bool MAYBE_DC = true>
 __device__ __forceinline__ uint32_t stream_mag_run(const BatchArgs &a, int64_t s, float2 &z, int64_t &zpos) {
     if (s < 0) return 0;
     if (s < (int64_t)kTrailing) {
@@ -156,15 +179,15 @@ __device__ __forceinline__ uint32_t stream_mag_run(const BatchArgs &a, int64_t s
     }
     s -= kTrailing;
     if ((uint64_t)s >= a.n) return 0;
-    if constexpr (FMT == kFmtSC16 || FMT == kFmtSC16Q11) {
+    if constexpr (FMT != kFmtMag16 && MAYBE_DC) {
         if (a.dc_local) {
-            const uint32_t *iq = (const uint32_t *)a.iq;
+            const auto raw = [&](int64_t j) -> uint32_t { return FMT == kFmtUC8 ? (uint32_t)((const uint16_t *)a.iq)[j] : ((const uint32_t *)a.iq)[j]; };
             if (s != zpos || (s & 7) == 0) {
                 z = dc_state_before_chunk(a, (uint64_t)s >> 3);
-                for (int64_t j = s & ~(int64_t)7; j < s; ++j) (void)dc_sample<FMT>(iq[j], a.dc_a, a.dc_b, z);
+                for (int64_t j = s & ~(int64_t)7; j < s; ++j) (void)dc_sample<FMT>(raw(j), a.dc_a, a.dc_b, z);
             }
             zpos = s + 1;
-            return dc_sample<FMT>(iq[s], a.dc_a, a.dc_b, z);
+            return dc_sample<FMT>(raw(s), a.dc_a, a.dc_b, z);
         }
     }
     return mag_of<FMT>(a.iq, (uint64_t)s, a.tab.uc8_lut);
@@ -821,7 +844,7 @@ __device__ void slow_offset(const BatchArgs &a, const uint16_t *m, uint32_t j, i
 
 // magnitudes of a whole region the slow way (per sample, any alignment, zero outside the stream): the first strip
 // of a batch (carry), the last ones (end of the stream) and unaligned input
-template <int FMT>
+template <int FMT, bool DC>
 __device__ void fill_region_general(const BatchArgs &a, uint16_t *m, int64_t s0, uint32_t lane) {
     for (int v = (int)lane; v < kRegion / 8; v += 64) {
         const int64_t s = s0 + 8 * v;
@@ -829,7 +852,7 @@ __device__ void fill_region_general(const BatchArgs &a, uint16_t *m, int64_t s0,
         float2 z = make_float2(0.0f, 0.0f);
         int64_t zpos = -1;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) e[k] = stream_mag_run<FMT>(a, s + k, z, zpos) ^ kBias;
+        for (int k = 0; k < 8; ++k) e[k] = stream_mag_run<FMT, DC>(a, s + k, z, zpos) ^ kBias;
         ((uint4 *)m)[v] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
     }
 }
@@ -837,13 +860,13 @@ __device__ void fill_region_general(const BatchArgs &a, uint16_t *m, int64_t s0,
 // The scan of one batch by the workgroups [0, n_regions / 16) given to it; `group` = this workgroup's number among them.
 template <int FMT, bool DC = false>
 __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t group) {
-    static_assert(!DC || FMT == kFmtSC16 || FMT == kFmtSC16Q11, "the DC block inside the scan: 16-bit formats");
+    static_assert(!DC || FMT != kFmtMag16, "the DC block inside the scan: raw sample formats");
     extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
     ScanShared &sh = *reinterpret_cast<ScanShared *>(scan_lds);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform: SGPR
     const uint64_t wave_t0 = a.wave_times ? wall_clock64() : 0;
 
-    if (FMT == kFmtUC8) load_radial_table(sh.lut, a.tab.uc8_radial, kBias2, tid, kScanThreads);
+    if (FMT == kFmtUC8 && !DC) load_radial_table(sh.lut, a.tab.uc8_radial, kBias2, tid, kScanThreads);
     for (uint32_t i = tid; i < 2 * kBloomWords; i += kScanThreads) sh.bloom[0][i] = 0;
     for (uint32_t i = tid; i < 160; i += kScanThreads) {
         const uint32_t row = i >> 4, e = i & 15;
@@ -990,7 +1013,16 @@ __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t gro
         bool general = !interior(strip);  // wave-uniform
         if (!general) {
             lut_min = 0x7fff7fffu;
-            if constexpr (FMT == kFmtUC8) {
+            if constexpr (DC) {
+                // (an interior strip: its first raw sample is a multiple of 8, so a lane's 8 samples are one chunk of the filter's states)
+                const uint64_t chunk0 = (uint64_t)(((int64_t)((uint64_t)strip * kStrip) - kTileShift - (int64_t)kTrailing) >> 3) + lane;
+#pragma unroll
+                for (int t = 0; t < kPasses; ++t) {
+                    const uint4 o = dc_chunk<FMT>(a, pre[t][0], pre[t][kRawVecs - 1], chunk0 + 64u * (uint32_t)t);
+                    ((uint4 *)W.m)[(int)lane + 64 * t] = o;
+                    take_chunk(t, o);
+                }
+            } else if constexpr (FMT == kFmtUC8) {
                 const uint32_t lut_lds = (uint32_t)(uintptr_t)sh.lut;
                 RadialChunk rc[2];
                 if (RSB_RADIAL_DEPTH == 2) radial_issue(pre[0][0], lut_lds, rc[0]);
@@ -1009,15 +1041,6 @@ __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t gro
                     ((uint4 *)W.m)[(int)lane + 64 * t] = o;
                     take_chunk(t, o);
                 }
-            } else if constexpr (DC) {
-                // (an interior strip: its first raw sample is a multiple of 8, so a lane's 8 samples are one chunk of the filter's states)
-                const uint64_t chunk0 = (uint64_t)(((int64_t)((uint64_t)strip * kStrip) - kTileShift - (int64_t)kTrailing) >> 3) + lane;
-#pragma unroll
-                for (int t = 0; t < kPasses; ++t) {
-                    const uint4 o = dc_chunk<FMT>(a, pre[t][0], pre[t][kRawVecs - 1], chunk0 + 64u * (uint32_t)t);
-                    ((uint4 *)W.m)[(int)lane + 64 * t] = o;
-                    take_chunk(t, o);
-                }
             } else {
 #pragma unroll
                 for (int t = 0; t < kPasses; ++t) {
@@ -1026,7 +1049,7 @@ __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t gro
                     take_chunk(t, o);
                 }
             }
-            if constexpr (FMT == kFmtUC8) {
+            if constexpr (FMT == kFmtUC8 && !DC) {
                 // a sample of the strip read an entry the radial table cannot hold (about one strip in fifteen on strong signals):
                 // those samples get their magnitude from the full table in global memory, the comparisons are taken again from LDS
                 const bool hit = (int16_t)lut_min == (int16_t)kRadialSentinel || (int16_t)(lut_min >> 16) == (int16_t)kRadialSentinel;
@@ -1065,7 +1088,7 @@ __device__ __forceinline__ void scan_body(const BatchArgs &a, const uint32_t gro
             for (int i = 0; i < 4; ++i) acc[i] = 0;
             general_strips += 1;
             wave_sync();
-            fill_region_general<FMT>(a, W.m, s0, lane);
+            fill_region_general<FMT, DC>(a, W.m, s0, lane);
             wave_sync();
 #pragma unroll
             for (int t = 0; t < kPasses; ++t) take_chunk(t, ((const uint4 *)W.m)[(int)lane + 64 * t]);
@@ -1882,7 +1905,10 @@ __device__ __forceinline__ void replay_blkbase_body(const ReplayArgs &r) {
 //         reproduces this table and the iteration ends after one round.  Any fixed point is the reference's result -- by induction
 //         over the offsets: what happens at offset g depends only on entries below g -- so the start affects the rounds only);
 //   else: the items the walk accepted, into the next table.
-constexpr int kMinSlots = 2048, kMinItemsPerGroup = 8192;
+#ifndef RSB_MIN_ITEMS
+#define RSB_MIN_ITEMS 2048  // (8192: 100 workgroups per Gsample of the benchmark traffic; 2048 measured 20 us faster over the two passes, 1024 no better)
+#endif
+constexpr int kMinSlots = 2048, kMinItemsPerGroup = RSB_MIN_ITEMS;
 template <bool SEED>
 __device__ __forceinline__ void replay_table_min_body(const ReplayArgs &r) {
     __shared__ uint32_t key[kMinSlots], val[kMinSlots];
@@ -2014,11 +2040,11 @@ typedef uint4 __attribute__((aligned(4))) uint4_a4;
 
 template <int FMT, bool DC = false>
 __device__ __forceinline__ void replay_emit_body(const BatchArgs &a, const ReplayArgs &r) {
-    static_assert(!DC || FMT == kFmtSC16 || FMT == kFmtSC16Q11, "the DC block inside the kernels: 16-bit formats");
+    static_assert(!DC || FMT != kFmtMag16, "the DC block inside the kernels: raw sample formats");
     extern __shared__ __attribute__((aligned(16))) unsigned char emit_lds[];  // 66 KB: over the static limit
     EmitShared &sh = *reinterpret_cast<EmitShared *>(emit_lds);
     constexpr uint32_t kT = 64 * kEmitWaves;
-    if (FMT == kFmtUC8) load_radial_table(sh.lut, a.tab.uc8_radial, kBias2, threadIdx.x, kT);  // the scan kernel's radial table
+    if (FMT == kFmtUC8 && !DC) load_radial_table(sh.lut, a.tab.uc8_radial, kBias2, threadIdx.x, kT);  // the scan kernel's radial table
     for (uint32_t i = threadIdx.x; i < 160; i += kT) {
         const uint32_t row = i >> 4, e = i & 15;
         sh.coef[row][e] = e < 15 ? coef_entry((int)(row / 5), (int)(row % 5), (int)(e / 3), (int)(e % 3)) : 0u;
@@ -3381,7 +3407,7 @@ hipError_t launch_scan(const BatchArgs &a, int grid, hipStream_t s) {
     if ((uint64_t)grid > need) grid = (int)need;
     return by_format(a.fmt, [&](auto F) {
         constexpr int f = decltype(F)::value;
-        if constexpr (f == kFmtSC16 || f == kFmtSC16Q11) {
+        if constexpr (f != kFmtMag16) {
             if (a.dc_local) {  // the DC block inside the scan
                 auto kern = k_scan<f, true>;
                 hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanShared));
@@ -3553,7 +3579,7 @@ hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream
         // grid for a quarter of the bound (the kernel strides over whatever the count turns out to be)
         const unsigned g = (r.n_items / 4 + 64 * kEmitWaves - 1) / (64 * kEmitWaves);
         const dim3 grid(g < 1 ? 1 : (g > (unsigned)kEmitGroups ? (unsigned)kEmitGroups : g));
-        if constexpr (f == kFmtSC16 || f == kFmtSC16Q11) {
+        if constexpr (f != kFmtMag16) {
             if (a.dc_local) {  // the DC block inside the kernel
                 auto kern = k_replay_emit<f, true>;
                 const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmitShared));
@@ -3874,7 +3900,7 @@ __global__ __launch_bounds__(kThreads) void k_dc_materialize(const BatchArgs a, 
 hipError_t launch_dc_carry(const BatchArgs &a, uint16_t *carry_out, hipStream_t s) {
     return by_format(a.fmt, [&](auto F) {
         constexpr int f = decltype(F)::value;
-        if constexpr (f == kFmtSC16 || f == kFmtSC16Q11) {
+        if constexpr (f != kFmtMag16) {
             hipLaunchKernelGGL(k_dc_carry<f>, dim3((kTrailing + kThreads - 1) / kThreads), dim3(kThreads), 0, s, a, carry_out);
             return hipGetLastError();
         } else {
@@ -3887,7 +3913,7 @@ hipError_t launch_dc_materialize(const BatchArgs &a, uint16_t *mag, hipStream_t 
     if (a.n == 0) return hipSuccess;
     return by_format(a.fmt, [&](auto F) {
         constexpr int f = decltype(F)::value;
-        if constexpr (f == kFmtSC16 || f == kFmtSC16Q11) {
+        if constexpr (f != kFmtMag16) {
             hipLaunchKernelGGL(k_dc_materialize<f>, dim3((unsigned)((a.n / 8 + kThreads) / kThreads)), dim3(kThreads), 0, s, a, mag);
             return hipGetLastError();
         } else {
@@ -3903,7 +3929,7 @@ hipError_t launch_dc_states(int fmt, const void *iq, uint64_t n, double2 *tile_s
     const uint32_t ntiles = (uint32_t)((n + kDcTile - 1) / kDcTile);
     return by_format(fmt, [&](auto F) {
         constexpr int f = decltype(F)::value;
-        if constexpr (f == kFmtSC16 || f == kFmtSC16Q11) {
+        if constexpr (f != kFmtMag16) {
             hipLaunchKernelGGL(k_dc_tile_sums<f>, dim3(ntiles), dim3(kThreads), 0, s, iq, n, (double)dc_a, (double)dc_b, tile_sums, local);
             const uint32_t nchunks = (ntiles + kDcChunkTiles - 1) / kDcChunkTiles;
             hipLaunchKernelGGL(k_dc_scan_local, dim3(nchunks), dim3(kDcChunkTiles), 0, s, tile_sums, tile_start, ntiles, (double)dc_b);

@@ -113,7 +113,7 @@ struct BatchArgs {
     int debug_flags;         // ablation only (RSB_ABL): 1 skip classify, 2 skip slicing loads, 4 skip reductions
     int stage_limit;         // debug/ablation only (RSB_STAGE_LIMIT): stop the scan kernel after stage k
     uint32_t block_len;      // samples per demodulator call (mag_buf.length of a full buffer): 131072 unless the source builds other buffers
-    // --dcfilter inside the scan (SC16 / SC16Q11; DESIGN.md "DC block, fused"): the filter state before every 8-sample chunk of iq is
+    // --dcfilter inside the scan (DESIGN.md "DC block, fused"): the filter state before every 8-sample chunk of iq is
     // (float)(dc_local[chunk] + dc_tile_start[chunk / 512] * dc_pow[chunk % 512]); the samples of a chunk then go through the
     // reference's float recurrence (convert.c:137-140) from there.  Null dc_local: no DC filter in the scan.
     const float2 *dc_local;        // per chunk: the state before it had the chunk's 4096-sample tile started from zero

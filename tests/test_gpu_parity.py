@@ -103,9 +103,9 @@ def test_dcfilter_block_means_are_the_same_bits_every_run(built):
     assert runs[0] == runs[1] == runs[2] and np.frombuffer(runs[0], dtype=np.float64).min() > 0
 
 
-@pytest.mark.parametrize("name", ["sc16_dc", "sc16_dc_highsnr"])
+@pytest.mark.parametrize("name", ["sc16_dc", "sc16_dc_highsnr", "uc8_dc"])
 def test_dcfilter_inside_the_scan_in_batches(name, built):
-    """--dcfilter on a 16-bit format without Mode A/C runs with the DC block inside the kernels (no magnitude buffer: a pass over the IQ
+    """--dcfilter without Mode A/C runs with the DC block inside the kernels (no magnitude buffer: a pass over the IQ
     leaves the filter's state per 8-sample chunk, every kernel takes its samples through convert.c:137-140 from there).  In batches of
     two blocks: the filter state and the 326-sample overlap (kept as magnitudes) cross the batch boundaries.  The magnitudes the
     library reports for each batch (made on request by the same routine) are within 1 LSB of the exact recurrence over the WHOLE
@@ -116,18 +116,20 @@ def test_dcfilter_inside_the_scan_in_batches(name, built):
     sc, kw = SCENARIOS[name]
     iq = generate(sc)
     n, nb = sc.n_samples, 2 * 131072
+    bps = 2 if sc.fmt == "UC8" else 4
     dev = torch.from_numpy(np.ascontiguousarray(iq)).cuda()
     ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=False, dc_filter=True, max_batch_samples=nb)
     parts, mags = [], []
     for a in range(0, n, nb):
         k = min(nb, n - a)
-        ch.submit(dev.data_ptr() + 4 * a, k)
+        ch.submit(dev.data_ptr() + bps * a, k)
         parts.append(ch.collect(cap=1 << 14).copy())
         mags.append(ch.batch_magnitudes(k)[0])
     ch.close()
     mag = np.concatenate(mags)
     got = np.concatenate(parts).view(REC_DTYPE)
-    x = (iq.reshape(n, 2).astype(np.float32) / np.float32(32768.0)).astype(np.float64)
+    raw = iq.reshape(n, 2).astype(np.float32)
+    x = ((raw - np.float32(127.5)) / np.float32(127.5) if sc.fmt == "UC8" else raw / np.float32(32768.0)).astype(np.float64)
     dc_b = float(np.float32(np.exp(-2.0 * np.pi / 2.4e6)))
     dc_a = float(np.float32(1.0 - dc_b))
     y = x - lfilter([dc_a], [1.0, -dc_b], x, axis=0)
@@ -142,7 +144,7 @@ def test_dcfilter_inside_the_scan_in_batches(name, built):
     ch.submit(dev.data_ptr(), cuts[1])
     for i in range(1, len(cuts)):
         if i + 1 < len(cuts):
-            ch.submit(dev.data_ptr() + 4 * cuts[i], cuts[i + 1] - cuts[i])
+            ch.submit(dev.data_ptr() + bps * cuts[i], cuts[i + 1] - cuts[i])
         again.append(ch.collect(cap=1 << 14).copy())
     ch.close()
     assert np.concatenate(again).tobytes() == np.concatenate(parts).tobytes()
