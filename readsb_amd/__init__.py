@@ -178,6 +178,8 @@ def collect_many(chans, outs, wait=True):
     cnt = (_SZ * n)()
     rc = (chans[0].l.rsb_collect_many if wait else chans[0].l.rsb_collect_many_begin)(ctx, n, op, cap, cnt)
     if rc != 0:
+        for c in chans:  # (a copy left in flight must not outlive the buffers the exception lets go of)
+            c.l.rsb_collect_wait(c.h)
         raise RsbError(f"rsb_collect_many: {rc}")
     return [o[:int(k)] for o, k in zip(outs, cnt)]
 
