@@ -1019,42 +1019,41 @@ int device_merge_modeac(rsb_ctx *c, rsb_slot &b, uint32_t nacc, size_t nblocks, 
     return 1;
 }
 
-int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRequest *wire) {
-    if (n_out) *n_out = 0;
-    if (!c->any_pending()) {
-        c->err = "rsb_collect: nothing submitted";
-        return RSB_ESTATE;
-    }
-    rsb_slot &b = c->collect_slot();
-    b.pending = false;
-    ++c->collected;
-    c->last_n = b.pending_n;
-    c->last_args = b.pending_args;
-    c->last_list_dev = nullptr;
-    c->last_items_info = nullptr;
-    c->last_g0 = b.g0;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    // everything from here on runs on the context's own stream, behind this batch's scan and beside the next batch's
-    // (rsb_collect_many: the channels' shared chain ran on one stream, and whatever is left to do for this channel follows it there)
-    hipStream_t s = c->chain_stream ? c->chain_stream : c->replay_stream;
-    HIP_TRY(c, hipStreamWaitEvent(s, b.ev[3], 0));
-    if (!b.chain_enqueued) HIP_TRY(c, hipEventRecord(b.rev[0], s));  // (collect_ahead has recorded it otherwise)
-    if (c->run_modes && !b.pruned && !b.chain_enqueued) {  // against the superset as it is now (the caller may have widened it)
-        const int rc = enqueue_prune(c, b, b.pending_args, s);
-        if (rc != RSB_OK) return rc;
-    }
-    const BatchArgs &a = b.pending_args;
-    const size_t nblocks = (size_t)((b.pending_n + c->block_len - 1) / c->block_len);
-    c->h_blk_counts.resize(nblocks + 1);
+// One rsb_collect, in phases that hand their results to each other through this:
+//   replay()      prune + replay of the batch -- the one-wait chain, or step by step (sort fallback, records straight to the caller's
+//                 buffer), or the candidate records for the host replay -- and the overflow checks
+//   fetch()       the finished list to the caller (device merge with Mode A/C, wire encoding, record copy), or the candidates to the host
+//   stage_times() the batch's events -> rsb_timing
+//   host_list()   what the device did not deliver: Mode A/C merge on the host, host replay
+//   account()     statistics, stream position, the caller's buffer
+struct CollectRun {
+    rsb_ctx *c;
+    rsb_slot &b;
+    hipStream_t s;
+    rsb_message *out;
+    size_t cap;
+    WireRequest *wire;
+    const BatchArgs &a;
+    size_t nblocks;
     int on_device = 0, direct_parts = 0;
-    c->timing.replay_iterations = 0;
-    uint32_t cnt[kCntCount];
-    std::memset(cnt, 0, sizeof(cnt));
+    uint32_t cnt[kCntCount] = {};
+    bool replayed = false, chain_ran = false;
+    uint32_t n_items = 0, nsurv = 0, nac = 0;
+    size_t n = 0;            // messages of this batch
+    bool delivered = false;  // already in out[]
+
+    int replay();
+    int fetch();
+    void stage_times();
+    int host_list();
+    int account(size_t *n_out);
+};
+
+int CollectRun::replay() {
     // The usual batch needs no word from the device before its replay is enqueued: the prune leaves the kept items packed in
     // order and their number in the counters, the replay kernels read it there, and the host waits ONCE, for the first
     // round's results and the counters together.  Anything unusual (a scan wavefront overflowed an LDS queue, a device queue
     // is full, marker items, host replay, records written straight to the caller's buffer) takes the step-by-step path below.
-    bool replayed = false, chain_ran = false;
     if (b.chain_enqueued || chain_needs_no_host(c, b)) {
         chain_ran = true;
         if (!b.chain_enqueued) {
@@ -1096,7 +1095,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         c->finished = true;
         return RSB_EOVERFLOW;
     }
-    uint32_t n_items = cnt[kCntSurvItems];
+    n_items = cnt[kCntSurvItems];
     if (!replayed) {
         if (b.pruned_in_order && cnt[kCntItems] != 0 && c->run_modes) {
             // a scan wavefront overflowed an LDS queue: its per-thread path put items into the shared region, out of order.  Prune once
@@ -1137,7 +1136,6 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
             if (!on_device) direct_parts = 0;  // (whatever the kernel wrote to the buffer, the host path rewrites it)
         }
     }
-    uint32_t nsurv = 0;
     if (!on_device) {
         // kept items -> distinct offsets -> full candidate records for the host replay
         HIP_TRY(c, launch_unique_finalize(a, n_items, c->sorted_buf, c->d_sort_temp, c->sort_temp_bytes, s));
@@ -1162,12 +1160,14 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         return RSB_EOVERFLOW;
     }
 
+    return RSB_OK;
+}
+
+int CollectRun::fetch() {
     const auto t_copy = std::chrono::steady_clock::now();
-    const uint32_t nac = cnt[kCntAc];
+    nac = cnt[kCntAc];
     c->h_ac.resize(nac);
     if (nac) HIP_TRY(c, hipMemcpyAsync(c->h_ac.data(), b.d_ac, nac * sizeof(AcCand), hipMemcpyDeviceToHost, s));
-    size_t n = 0;            // messages of this batch
-    bool delivered = false;  // already in out[]
     rsb_stats &st = c->replay.stats();
     if (on_device) {
         const uint32_t nacc = cnt[kCntAccepted];
@@ -1223,6 +1223,10 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     }
     c->timing.copy_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_copy).count();
 
+    return RSB_OK;
+}
+
+void CollectRun::stage_times() {
     float ms = 0;
     c->timing.scan_ms = c->timing.modeac_ms = c->timing.total_ms = 0;
     if (b.scan_timed) {  // (a channel of rsb_submit_many's one launch other than the first: the launch's time is reported there)
@@ -1242,6 +1246,9 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     c->timing.total_ms += c->timing.sort_ms + ms;
     c->timing.replay_on_device = on_device;
 
+}
+
+int CollectRun::host_list() {
     const auto t0 = std::chrono::steady_clock::now();
     if (!delivered) {
         c->msgs.clear();
@@ -1279,6 +1286,11 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     }
 #endif
 
+    return RSB_OK;
+}
+
+int CollectRun::account(size_t *n_out) {
+    rsb_stats &st = c->replay.stats();
     if (on_device && chain_ran && c->run_modes) {  // the kept items the replay worked on stay where they are until this slot is scanned again
         c->last_items_info = b.chain_r.info;
         c->last_items_n = b.chain_r.n_items;
@@ -1325,6 +1337,43 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
         return RSB_EOVERFLOW;
     }
     return RSB_OK;
+}
+
+int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRequest *wire) {
+    if (n_out) *n_out = 0;
+    if (!c->any_pending()) {
+        c->err = "rsb_collect: nothing submitted";
+        return RSB_ESTATE;
+    }
+    rsb_slot &b = c->collect_slot();
+    b.pending = false;
+    ++c->collected;
+    c->last_n = b.pending_n;
+    c->last_args = b.pending_args;
+    c->last_list_dev = nullptr;
+    c->last_items_info = nullptr;
+    c->last_g0 = b.g0;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    // everything from here on runs on the context's own stream, behind this batch's scan and beside the next batch's
+    // (rsb_collect_many: the channels' shared chain ran on one stream, and whatever is left to do for this channel follows it there)
+    hipStream_t s = c->chain_stream ? c->chain_stream : c->replay_stream;
+    HIP_TRY(c, hipStreamWaitEvent(s, b.ev[3], 0));
+    if (!b.chain_enqueued) HIP_TRY(c, hipEventRecord(b.rev[0], s));  // (collect_ahead has recorded it otherwise)
+    if (c->run_modes && !b.pruned && !b.chain_enqueued) {  // against the superset as it is now (the caller may have widened it)
+        const int rc = enqueue_prune(c, b, b.pending_args, s);
+        if (rc != RSB_OK) return rc;
+    }
+    CollectRun run{c, b, s, out, cap, wire, b.pending_args, (size_t)((b.pending_n + c->block_len - 1) / c->block_len)};
+    c->h_blk_counts.resize(run.nblocks + 1);
+    c->timing.replay_iterations = 0;
+    int rc = run.replay();         // the batch's messages decided: on the device (records in b.d_out), or candidates for the host
+    if (rc != RSB_OK) return rc;
+    rc = run.fetch();              // ... and brought to where they are wanted
+    if (rc != RSB_OK) return rc;
+    run.stage_times();
+    rc = run.host_list();          // (only what the device did not deliver)
+    if (rc != RSB_OK) return rc;
+    return run.account(n_out);
 }
 
 }  // namespace
