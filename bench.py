@@ -222,8 +222,9 @@ def main() -> int:
     ap.add_argument("--steps-in-flight", type=int, default=2, choices=(1, 2),
                     help="2: step k + 1 (its own receiver channel) is submitted before step k is collected, so the replay / copy tail of one "
                          "recording runs beside the scan of the next; 1: strictly one step at a time")
-    ap.add_argument("--fence", type=int, default=1, choices=(0, 1),
-                    help="with two steps in flight: queue the next step's scan behind this step's chain on the device (rsb_collect_fence)")
+    ap.add_argument("--fence", type=int, default=0, choices=(0, 1),
+                    help="with two steps in flight: queue the next step's scan behind this step's chain on the device (rsb_collect_fence); "
+                         "default off: measured 2.34 against 1.97 ms per step without it (profiles/r3_step_modes.txt)")
     ap.add_argument("--scan-workgroups", type=int, default=-1, help="rsb_config.scan_workgroups: CUs the persistent scan kernel takes; -1 = all with one batch, "
                     "224 with several (one CU per shader engine stays free for the replay kernels of the batch before)")
     ap.add_argument("--output", choices=("records", "beast", "raw"), default="records",
@@ -233,8 +234,7 @@ def main() -> int:
     # the other BASELINE.json configurations (the default line stays configs[1]); parity for each is covered in tests/
     ap.add_argument("--format", choices=("UC8", "SC16", "SC16Q11"), default="UC8", help="configs[2]: 4-byte samples (bladeRF / Pluto)")
     ap.add_argument("--submit-ahead", type=int, default=-1, choices=(-1, 0, 1),
-                    help="two steps in flight: submit step k + 1 before waiting for step k's chain (default: with --dcfilter, "
-                         "where the pass that leaves the filter's states -- bound by HBM -- then runs beside step k's prune / replay / emit)")
+                    help="two steps in flight: submit step k + 1 before waiting for step k's chain (default off: measured slower)")
     ap.add_argument("--dcfilter", action="store_true", help="configs[2]: the DC-block IIR as a chunked scan")
     ap.add_argument("--modeac", action="store_true", help="configs[4]: also demodulate2400AC")
     ap.add_argument("--fix-bits", type=int, default=1, choices=(0, 1, 2), help="0 --no-fix, 1 --fix (default), 2 --aggressive (configs[4])")
@@ -300,7 +300,7 @@ def main() -> int:
     # contexts keep the converter and its one magnitude buffer: one step at a time
     dc_fused = args.dcfilter and not args.modeac and not os.environ.get("RSB_DC_UNFUSED")
     if args.submit_ahead < 0:
-        args.submit_ahead = 1 if dc_fused else 0
+        args.submit_ahead = 0  # (measured: the next step's scan takes every CU and starves this step's chain -- 4.7 instead of 4.1 ms with --dcfilter)
     overlap = args.steps_in_flight == 2 and C == 1 and nb == 1 and args.output == "records" and (not args.dcfilter or dc_fused)
     scan_wgs = args.scan_workgroups if args.scan_workgroups >= 0 else (0 if nb == 1 else 224)
     chans = [readsb_amd.Channel(fmt=args.format, fix_bits=args.fix_bits, mode_ac=args.modeac, dc_filter=args.dcfilter, device=local_rank,
