@@ -315,6 +315,9 @@ def main() -> int:
                                  scan_workgroups=scan_wgs) for _ in range(C if overlap_many else 0)]
     ch = chans[0]
     stream = torch.cuda.current_stream().cuda_stream
+    if os.environ.get("RSB_BENCH_OWN_STREAM"):  # (measurement: submits on a stream of their own instead of the default stream)
+        own_stream = torch.cuda.Stream()
+        stream = own_stream.cuda_stream
     cap = max(1 << 16, n // (256 if args.dense else 512))
     # the caller's result buffer: pinned, so the device -> host copy of the message list runs at link speed
     outbuf = torch.empty(cap * readsb_amd.MSG_DTYPE.itemsize, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE)
@@ -430,10 +433,22 @@ def main() -> int:
         out = None
         chans[0].reset()
         chans[0].submit(base, nc, stream)
+        trace = os.environ.get("RSB_BENCH_TRACE")  # (measurement: where the host spends a step, averaged, to stderr)
+        spent, mark = {}, time.perf_counter()
+
+        def lap(what):
+            nonlocal mark
+            if trace:
+                now = time.perf_counter()
+                spent[what] = spent.get(what, 0.0) + now - mark
+                mark = now
+
         for k in range(count):
             c, o = chans[k % 2], chans[(k + 1) % 2]
+            lap("loop")
             if k > 0:
                 o.collect_wait()               # step k - 1's records are in host memory (their copy ran beside step k's scan)
+            lap("collect_wait")
             if args.fence:
                 # step k's chain goes onto its stream now, and step k + 1's scan is queued behind it ON THE DEVICE: the GPU goes
                 # from emit k to scan k + 1 without waiting for the host to notice that step k is done
@@ -446,16 +461,21 @@ def main() -> int:
             else:
                 if k + 1 < count:
                     o.reset()                      # the other channel's next recording starts cold; done while step k's scan runs
+                lap("reset")
                 if args.submit_ahead and k + 1 < count:
                     o.submit(base, nc, stream)     # step k + 1 queued behind step k's scan: its first kernels run beside step k's chain
                 out = c.collect_begin(bufs[k % 2])  # waits for step k's scan, prune, replay and emit; its copy is under way
+                lap("collect_begin")
                 if not args.submit_ahead and k + 1 < count:
                     o.submit(base, nc, stream)
+                lap("submit")
             if tm is not None:
                 t = c.timing()
                 for key in keys:
                     tm[key].append(t[key])
         chans[(count - 1) % 2].collect_wait()
+        if trace and tm is not None:
+            print("host ms per step: " + ", ".join(f"{k} {v / count * 1e3:.3f}" for k, v in spent.items()), file=sys.stderr)
         chan_msgs[1] = out.size
         return out
 
