@@ -333,8 +333,7 @@ int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devi
     // point): one wait for "did the table move" and the counters together.  If it did move, those records are discarded,
     // the iteration goes on and they are written again.
     HIP_TRY(c, launch_replay_iteration(a, r, s));
-    b.h_pin[0] = 0;
-    HIP_TRY(c, hipMemcpyAsync(&b.h_pin[0], b.d_counters + kCntChanged, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    // ("did the table move" comes back with the counters: nothing behind k_replay_compare touches that word)
     HIP_TRY(c, launch_replay_select(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
     HIP_TRY(c, launch_replay_emit(a, r, s));
     if ((rc = enqueue_readbacks(c, b, r, s)) != RSB_OK) return rc;
@@ -364,7 +363,7 @@ int replay_finish(rsb_ctx *c, rsb_slot &b, hipStream_t s, uint32_t cnt[kCntCount
             HIP_TRY(c, hipMemcpyAsync(&pin[0], b.d_counters + kCntChanged, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         }
         HIP_TRY(c, hipStreamSynchronize(s));
-        const uint32_t changed = pin[0];
+        const uint32_t changed = it == 0 ? pin[1 + kCntChanged] : pin[0];
         if (it == 0) {
             std::memcpy(cnt, pin + 1, kCntCount * sizeof(uint32_t));
             std::memcpy(c->h_blk_counts.data(), pin + 1 + kCntCount, r.nblocks * sizeof(uint32_t));

@@ -1875,6 +1875,7 @@ __device__ __forceinline__ void replay_walk_body(const ReplayArgs &r) {
 __device__ __forceinline__ void replay_blkbase_body(const ReplayArgs &r) {
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x, per = (r.nblocks + 1023) / 1024, lo = min(r.nblocks, t * per), hi = min(r.nblocks, lo + per);
+    if (t < 4) r.counters[kCntNewAdders + t] = 0;  // new adders, accepted by errors: k_replay_list / k_replay_emit count them (a repeated round starts over)
     uint32_t sum = 0;
     for (uint32_t b = lo; b < hi; ++b) sum += r.blk_counts[b];
     part[t] = sum;
@@ -2460,7 +2461,6 @@ __global__ __launch_bounds__(kThreads) void k_replay_compare_many(const ChainArg
 __global__ __launch_bounds__(1024) void k_replay_blkbase_many(const ChainArgs *__restrict__ m) {
     const ChainArgs &c = m[blockIdx.y];
     if (chain_idle(c)) return;
-    if (threadIdx.x < 4) c.r.counters[kCntNewAdders + threadIdx.x] = 0;  // (launch_replay_select's memset: new adders, accepted by errors)
     replay_blkbase_body(c.r);
 }
 __global__ __launch_bounds__(kThreads) void k_replay_list_many(const ChainArgs *__restrict__ m) {
@@ -3559,8 +3559,6 @@ hipError_t launch_replay_reset(const BatchArgs &, const ReplayArgs &r, uint32_t 
 }
 
 hipError_t launch_replay_select(const BatchArgs &a, const ReplayArgs &r, void *, size_t, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(&a.counters[kCntNewAdders], 0, 4 * sizeof(uint32_t), s);  // new adders, by errors (a repeated round starts over)
-    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_replay_blkbase, dim3(1), dim3(1024), 0, s, r);
     if (r.n_items) hipLaunchKernelGGL(k_replay_list, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, a.counters);
     return hipGetLastError();
