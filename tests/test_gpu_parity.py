@@ -962,6 +962,58 @@ def test_thirty_two_channels_share_one_chain(pessimistic, built, monkeypatch):
     assert sum(w.size for w in want) > 8000
 
 
+def test_many_channels_copies_left_in_flight(built):
+    """rsb_collect_many_begin: every channel's count is known and its record copy under way when the call returns; after
+    rsb_collect_wait on each channel the lists are those of rsb_collect_many -- also with the next batches submitted in between"""
+    import torch
+
+    nb = 2 * 131072
+    iqs = [generate(Scenario_for(k)) for k in range(4)]
+    devs = [torch.from_numpy(x).cuda() for x in iqs]
+    lists = {}
+    for wait in (True, False):
+        chans = [readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=nb) for _ in range(4)]
+        outs = [[torch.empty((1 << 13) * 56, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE) for _ in range(4)] for _ in range(2)]
+        got = [[] for _ in range(4)]
+        cuts = list(range(0, iqs[0].shape[0], nb)) + [iqs[0].shape[0]]
+        readsb_amd.submit_many(chans, [d.data_ptr() for d in devs], [cuts[1]] * 4)
+        pending = None
+        for b in range(len(cuts) - 1):
+            views = readsb_amd.collect_many(chans, outs[b % 2], wait=wait)
+            if b + 2 < len(cuts):
+                readsb_amd.submit_many(chans, [d.data_ptr() + 2 * cuts[b + 1] for d in devs], [cuts[b + 2] - cuts[b + 1]] * 4)
+            if pending is not None:
+                for k in range(4):
+                    got[k].append(pending[k].copy())
+                pending = None
+            if not wait:
+                for c in chans:
+                    c.collect_wait()
+            pending = views
+        for k in range(4):
+            got[k].append(pending[k].copy())
+        lists[wait] = [np.concatenate(g) for g in got]
+        for c in chans:
+            c.close()
+    for k in range(4):
+        want, _ = Oracle(fmt="UC8", nfix=1).run_stream(iqs[k])
+        assert first_mismatch(want, lists[True][k].view(REC_DTYPE)) is None
+        assert lists[True][k].tobytes() == lists[False][k].tobytes()
+
+
+def test_dcfilter_inside_the_kernels_with_host_replay(built):
+    """the candidate-record kernel (host replay path) takes its samples through the DC block as the scan does: same list as the device replay"""
+    sc, kw = SCENARIOS["sc16_dc"]
+    iq = generate(sc)
+    outs = []
+    for host_replay in (False, True):
+        ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=False, dc_filter=True, max_batch_samples=1 << 22, host_replay=host_replay)
+        outs.append(ch.process_host(iq))
+        assert ch.timing()["replay_on_device"] == (0 if host_replay else 1)
+        ch.close()
+    assert outs[0].size > 100 and outs[0].tobytes() == outs[1].tobytes()
+
+
 def Scenario_for(k):
     from readsb_amd.synth import Scenario
 
