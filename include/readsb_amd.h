@@ -51,7 +51,10 @@ enum {
 typedef struct rsb_config {
     int32_t input_format;      /* RSB_UC8 / RSB_SC16 / RSB_SC16Q11 */
     int32_t dc_filter;         /* --dcfilter (readsb.c:485-487): the DC-block IIR of convert.c:137-140 as a chunked scan; results
-                                  follow the reference within a tolerance, not bit for bit */
+                                  follow the reference within a tolerance, not bit for bit (DESIGN.md sections 5c, 7).  Without mode_ac
+                                  and RSB_FLAG_EXACT_STATS the filter runs inside the scan / candidate / record kernels (no magnitude
+                                  buffer, two batches in flight); with them a converter writes the batch's magnitudes first and one
+                                  batch is in flight.  rsb_seek is refused either way (the filter's state does not travel) */
     int32_t fix_bits;          /* Modes.nfix_crc: 0 (--no-fix), 1 (--fix, default), 2 (--aggressive) */
     int32_t mode_ac;           /* --modeac */
     int32_t device;            /* HIP device ordinal */
@@ -165,7 +168,8 @@ int rsb_create(const rsb_config *cfg, rsb_ctx **out);
 void rsb_destroy(rsb_ctx *ctx);
 
 /* Start a new recording: stream position 0, zero overlap (sdr_ifile.c:200-204), empty filter
- * (icaoFilterInit, icao_filter.c:65-69), counters cleared. */
+ * (icaoFilterInit, icao_filter.c:65-69), DC-block state zero (init_converter, convert.c:477), counters cleared.  The device side of
+ * it is enqueued on the context's own stream without a host wait; the next rsb_submit orders itself behind it. */
 int rsb_reset(rsb_ctx *ctx);
 
 /* icaoFilterAdd (icao_filter.c:71-95): what --show-only does at start-up (readsb.c:249-250). */
@@ -280,7 +284,10 @@ int rsb_process_host(rsb_ctx *ctx, const void *iq_host, uint64_t nsamples,
 
 /* --dcfilter and RSB_FLAG_SC16Q11_TABLE contexts only: the magnitudes the converter produced for the last collected batch (what
  * iq_convert_fn would have written, convert.c:113-423) and, if block_means != NULL and the context runs Mode A/C, mean level / mean
- * power of each of its 131072-sample blocks.  For checking the demodulators apart from the converter's tolerance. */
+ * power of each of its 131072-sample blocks.  For checking the demodulators apart from the converter's tolerance.
+ * A --dcfilter context whose kernels filter for themselves holds no magnitudes: they are made by this call, from the batch's samples
+ * (the caller's iq_dev, which must still be valid) and the filter states in the batch's slot, by the routine every kernel of the batch
+ * used; call it before the slot is used again (two batches later). */
 int rsb_get_batch_magnitudes(rsb_ctx *ctx, uint16_t *mag_host, uint64_t nsamples, double *block_means);
 
 /* ---- live sources: the producer half of the mag_buf ring ---------------------- */
