@@ -453,11 +453,14 @@ def main() -> int:
                 # step k's chain goes onto its stream now, and step k + 1's scan is queued behind it ON THE DEVICE: the GPU goes
                 # from emit k to scan k + 1 without waiting for the host to notice that step k is done
                 c.collect_prepare()
+                lap("collect_prepare")
                 if k + 1 < count:
                     o.reset()
                     c.collect_fence(stream)
                     o.submit(base, nc, stream)
+                lap("reset+fence+submit")
                 out = c.collect_begin(bufs[k % 2])
+                lap("collect_begin")
             else:
                 if k + 1 < count:
                     o.reset()                      # the other channel's next recording starts cold; done while step k's scan runs

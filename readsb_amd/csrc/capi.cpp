@@ -124,6 +124,7 @@ int setup_device(rsb_ctx *c) {
         HIP_TRY(c, hipMalloc((void **)&b.d_block_means, c->nblocks_cap * 2 * sizeof(double)));
         for (hipEvent_t &ev : b.ev) HIP_TRY(c, hipEventCreate(&ev));
         for (hipEvent_t &ev : b.rev) HIP_TRY(c, hipEventCreate(&ev));
+        HIP_TRY(c, hipEventCreateWithFlags(&b.chain_done, hipEventDisableTiming));
     }
     HIP_TRY(c, hipStreamCreateWithFlags(&c->replay_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -307,6 +308,7 @@ int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devi
     HIP_TRY(c, hipEventRecord(b.rev[1], s));
     if (r.nblocks == 0) {
         HIP_TRY(c, hipEventRecord(b.rev[2], s));
+        HIP_TRY(c, hipEventRecord(b.chain_done, s));
         return RSB_OK;
     }
     r.t_cur = c->d_first_add[c->first_cur];  // seeded with the optimistic "first added at" entries (k_replay_table_min<true>)
@@ -338,6 +340,7 @@ int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devi
     HIP_TRY(c, launch_replay_emit(a, r, s));
     if ((rc = enqueue_readbacks(c, b, r, s)) != RSB_OK) return rc;
     HIP_TRY(c, hipEventRecord(b.rev[2], s));
+    HIP_TRY(c, hipEventRecord(b.chain_done, s));  // (what rsb_collect_fence waits for: an event without timing)
     return RSB_OK;
 }
 
@@ -587,6 +590,7 @@ void rsb_destroy(rsb_ctx *c) {
             if (ev) (void)hipEventDestroy(ev);
         for (hipEvent_t ev : b.rev)
             if (ev) (void)hipEventDestroy(ev);
+        if (b.chain_done) (void)hipEventDestroy(b.chain_done);
         if (b.h_pin) (void)hipHostFree(b.h_pin);
     }
     if (c->replay_stream) (void)hipStreamDestroy(c->replay_stream);
@@ -1225,8 +1229,30 @@ int CollectRun::fetch() {
     return RSB_OK;
 }
 
+// RSB_GAP_TRACE=1 (measurement): per collected batch, device time between the stages' events -- also across contexts: from the end of
+// the chain collected before (whichever context's) to this batch's scan start
+static void gap_trace(const rsb_slot &b) {
+    static const bool on = std::getenv("RSB_GAP_TRACE") != nullptr;
+    if (!on) return;
+    static hipEvent_t last_chain_end = nullptr;
+    static double sum[4] = {0, 0, 0, 0};
+    static int n = 0;
+    float v = 0;
+    if (last_chain_end && hipEventElapsedTime(&v, last_chain_end, b.ev[0]) == hipSuccess) sum[0] += v;   // previous chain end -> scan start
+    if (hipEventElapsedTime(&v, b.ev[0], b.ev[1]) == hipSuccess) sum[1] += v;                            // scan
+    if (hipEventElapsedTime(&v, b.ev[1], b.rev[0]) == hipSuccess) sum[2] += v;                           // scan end -> chain start
+    if (hipEventElapsedTime(&v, b.rev[0], b.rev[2]) == hipSuccess) sum[3] += v;                          // chain
+    last_chain_end = b.rev[2];
+    if (++n % 8 == 0) {
+        std::fprintf(stderr, "gap trace (ms, mean of 8): chain end -> scan start %.3f | scan %.3f | scan end -> chain start %.3f | chain %.3f\n", sum[0] / 8, sum[1] / 8,
+                     sum[2] / 8, sum[3] / 8);
+        sum[0] = sum[1] = sum[2] = sum[3] = 0;
+    }
+}
+
 void CollectRun::stage_times() {
     float ms = 0;
+    gap_trace(b);
     c->timing.scan_ms = c->timing.modeac_ms = c->timing.total_ms = 0;
     if (b.scan_timed) {  // (a channel of rsb_submit_many's one launch other than the first: the launch's time is reported there)
         (void)hipEventElapsedTime(&c->timing.scan_ms, b.ev[0], b.ev[1]);
@@ -1410,7 +1436,7 @@ int rsb_collect_fence(rsb_ctx *c, void *stream) {
     rsb_slot &nb = c->collect_slot();
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     // behind the prepared chain's last kernel and readbacks; without a prepared chain, behind the batch's scan
-    HIP_TRY(c, hipStreamWaitEvent((hipStream_t)stream, nb.chain_enqueued ? nb.rev[2] : nb.ev[3], 0));
+    HIP_TRY(c, hipStreamWaitEvent((hipStream_t)stream, nb.chain_enqueued ? nb.chain_done : nb.ev[3], 0));
     return RSB_OK;
 }
 

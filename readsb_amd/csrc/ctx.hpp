@@ -29,6 +29,7 @@ struct rsb_slot {
     double *d_block_means = nullptr;  // SC16 / SC16Q11 with Mode A/C: the float converters' per-block means
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // scan start / end, prune end, Mode A/C end
     hipEvent_t rev[3] = {nullptr, nullptr, nullptr};          // collect side: sort start / end, replay end
+    hipEvent_t chain_done = nullptr;  // behind the enqueued chain's last operation (no timing: other streams wait for it on the device)
     // device replay of this batch (one set per slot: the chain of batch k + 1 is enqueued while batch k's records still leave)
     rsb_message *d_out = nullptr;     // the batch's message records
     uint32_t *d_blk_counts = nullptr, *d_blk_start = nullptr, *d_blk_base = nullptr;
