@@ -1654,7 +1654,10 @@ __device__ __forceinline__ void prune_offsets_body(const BatchArgs &a) {
 
 // Eight lanes per chunk: its kept items to their places.  Sub-lane l takes keep mask word l of the chunk (a chunk of two strips has
 // two or three), so the words and then the kept items of eight chunks are fetched side by side in a wavefront.
-constexpr int kWriteLanes = 8;
+#ifndef RSB_WRITE_LANES
+#define RSB_WRITE_LANES 8
+#endif
+constexpr int kWriteLanes = RSB_WRITE_LANES;
 __device__ __forceinline__ void prune_write_body(const BatchArgs &a) {
     const uint32_t sub = threadIdx.x & (kWriteLanes - 1), c = (blockIdx.x * kThreads + threadIdx.x) / kWriteLanes;
     const bool live = c < a.n_chunks;
