@@ -1937,6 +1937,7 @@ int rsb_convert_device(rsb_ctx *c, const void *iq_dev, void *mag_dev, uint64_t n
     if (!c || !iq_dev || !mag_dev) return RSB_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (c->reset_pending) HIP_TRY(c, hipStreamWaitEvent(s, c->reset_done, 0));  // (rsb_reset zeroes the DC state on the context's own stream)
     const bool want = mean_level || mean_power;
     if (c->cfg.dc_filter) {
         // convert.c:113-162 / :164-213 / :374-423 as a chunked scan; the DC state lives in the context, as in struct converter_state
