@@ -1382,6 +1382,7 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     // everything from here on runs on the context's own stream, behind this batch's scan and beside the next batch's
     // (rsb_collect_many: the channels' shared chain ran on one stream, and whatever is left to do for this channel follows it there)
     hipStream_t s = c->chain_stream ? c->chain_stream : c->replay_stream;
+    if (!c->chain_stream) c->own_stream_used = true;  // (work for the filter tables may be left on it when this call returns: the fold)
     HIP_TRY(c, hipStreamWaitEvent(s, b.ev[3], 0));
     if (!b.chain_enqueued) HIP_TRY(c, hipEventRecord(b.rev[0], s));  // (collect_ahead has recorded it otherwise)
     if (c->run_modes && !b.pruned && !b.chain_enqueued) {  // against the superset as it is now (the caller may have widened it)
@@ -1638,6 +1639,12 @@ static int run_one_chain(rsb_ctx *const *ctx, size_t nch) {
     for (size_t i = 0; i < nch; ++i) {
         const int rc = rsb_collect_wait(ctx[i]);  // (a record copy left in flight reads the d_out this chain writes, on one-slot contexts)
         if (rc != RSB_OK) return rc;
+        // a channel collected by itself before has left its last kernels (the fold into its filter tables) on its own stream, which
+        // the shared stream knows nothing of
+        if (ctx[i] != c0 && ctx[i]->own_stream_used) {
+            HIP_TRY(ctx[i], hipStreamSynchronize(ctx[i]->replay_stream));
+            ctx[i]->own_stream_used = false;
+        }
     }
     if (nch > c0->chain_args_cap) {
         if (c0->d_chain_args) (void)hipFree(c0->d_chain_args);

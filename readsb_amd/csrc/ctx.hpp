@@ -190,6 +190,7 @@ struct rsb_ctx {
     hipEvent_t many_args_read[2] = {nullptr, nullptr};
     bool many_args_pending[2] = {false, false};
     unsigned many_calls = 0;
+    bool own_stream_used = false;           // a collect of this channel alone has put work on replay_stream since rsb_collect_many last looked
     hipStream_t chain_stream = nullptr;     // set while rsb_collect_many collects this channel behind a chain shared with other channels
     rsb::ChainArgs *d_chain_args = nullptr, *h_chain_args = nullptr;  // rsb_collect_many: the channels' chain arguments (held by the first channel)
     uint32_t *d_chain_back = nullptr, *h_chain_back = nullptr;        // ... and what comes back of every channel, gathered

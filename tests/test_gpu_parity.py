@@ -962,6 +962,35 @@ def test_thirty_two_channels_share_one_chain(pessimistic, built, monkeypatch):
     assert sum(w.size for w in want) > 8000
 
 
+def test_shared_chain_and_single_collects_in_turn(built):
+    """channels collected through the shared chain (one stream for all), then each by itself (its own stream), then together again:
+    the filter tables follow from one stream to the other"""
+    import torch
+
+    nb = 2 * 131072
+    iqs = [generate(Scenario_for(k)) for k in range(4)]
+    devs = [torch.from_numpy(x).cuda() for x in iqs]
+    chans = [readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=nb) for _ in range(4)]
+    outs = [torch.empty((1 << 13) * 56, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE) for _ in range(4)]
+    got = [[] for _ in range(4)]
+    cuts = list(range(0, iqs[0].shape[0], nb)) + [iqs[0].shape[0]]
+    for b in range(len(cuts) - 1):
+        n = cuts[b + 1] - cuts[b]
+        if b % 2 == 0:
+            readsb_amd.submit_many(chans, [d.data_ptr() + 2 * cuts[b] for d in devs], [n] * 4)
+            for k, part in enumerate(readsb_amd.collect_many(chans, outs)):
+                got[k].append(part.copy())
+        else:
+            for k in range(4):
+                chans[k].submit(devs[k].data_ptr() + 2 * cuts[b], n)
+            for k in range(4):
+                got[k].append(chans[k].collect(cap=1 << 13).copy())
+    for k in range(4):
+        want, _ = Oracle(fmt="UC8", nfix=1).run_stream(iqs[k])
+        assert first_mismatch(want, np.concatenate(got[k]).view(REC_DTYPE)) is None
+        chans[k].close()
+
+
 def test_many_channels_copies_left_in_flight(built):
     """rsb_collect_many_begin: every channel's count is known and its record copy under way when the call returns; after
     rsb_collect_wait on each channel the lists are those of rsb_collect_many -- also with the next batches submitted in between"""
