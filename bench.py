@@ -233,6 +233,9 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # the other BASELINE.json configurations (the default line stays configs[1]); parity for each is covered in tests/
     ap.add_argument("--format", choices=("UC8", "SC16", "SC16Q11"), default="UC8", help="configs[2]: 4-byte samples (bladeRF / Pluto)")
+    ap.add_argument("--chain-on-submit-stream", type=int, default=0, choices=(0, 1),
+                    help="with two steps in flight: a step's prune / replay / emit chain on the stream its scan was submitted on "
+                         "(rsb_collect_prepare_on), the next step's scan behind it")
     ap.add_argument("--submit-ahead", type=int, default=-1, choices=(-1, 0, 1),
                     help="two steps in flight: submit step k + 1 before waiting for step k's chain (default off: measured slower)")
     ap.add_argument("--dcfilter", action="store_true", help="configs[2]: the DC-block IIR as a chunked scan")
@@ -449,7 +452,18 @@ def main() -> int:
             if k > 0:
                 o.collect_wait()               # step k - 1's records are in host memory (their copy ran beside step k's scan)
             lap("collect_wait")
-            if args.fence:
+            if args.chain_on_submit_stream:
+                # step k's chain goes onto the submit stream, right behind its scan, and step k + 1's scan behind the chain: scan, chain,
+                # scan, chain in one queue, no hop to another stream and no host turn-around between them
+                c.collect_prepare(on_stream=stream)
+                lap("collect_prepare")
+                if k + 1 < count:
+                    o.reset()
+                    o.submit(base, nc, stream)
+                lap("reset+submit")
+                out = c.collect_begin(bufs[k % 2])
+                lap("collect_begin")
+            elif args.fence:
                 # step k's chain goes onto its stream now, and step k + 1's scan is queued behind it ON THE DEVICE: the GPU goes
                 # from emit k to scan k + 1 without waiting for the host to notice that step k is done
                 c.collect_prepare()

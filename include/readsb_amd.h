@@ -238,6 +238,14 @@ int rsb_collect(rsb_ctx *ctx, rsb_message *out, size_t cap, size_t *n_out);
  * this call, or by the library itself for a batch submitted ahead -- discards that chain: the batch is pruned and replayed again when
  * it is collected, against the filter as it is then (what the reference's loop sees between two demodulate2400 calls). */
 int rsb_collect_prepare(rsb_ctx *ctx);
+/* The same with the chain on a stream of the caller's -- normally the one the batch was submitted on: the chain then follows the
+ * batch's scan in that stream with no hop to another queue, and whatever the caller submits on the stream next (the next batch's
+ * scan) follows the chain, so the GPU goes from scan to chain to scan without waiting for the host or for an event of another stream
+ * (measured: a chain on the context's own stream starts 25 us after its scan when the submit stream is idle by then, and ~0.5 ms
+ * after it when that stream already holds the next scan).  rsb_collect* of the batch waits for the chain's own
+ * event, not for the stream.  What a collect has to enqueue after the chain in unusual cases (further replay rounds, the Mode A/C
+ * merge on the device) goes to the same stream, behind whatever the caller has queued there meanwhile: correct, but late. */
+int rsb_collect_prepare_on(rsb_ctx *ctx, void *stream);
 /* N blocks x C channels in one call (last row): channel i's batch iq_dev[i][0 .. nsamples[i]) is submitted on
  * `stream` for every i, and rsb_collect_many fetches every channel's messages into out[i][0 .. cap[i]) (n_out[i] of them).
  * The channels are independent receivers (own filter, own stream position: ctx[i] from rsb_create), so this is rsb_submit /

@@ -96,6 +96,7 @@ SYMBOLS = {
     "rsb_collect_begin": (C.c_int, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_collect_wait": (C.c_int, [_VP]),
     "rsb_collect_prepare": (C.c_int, [_VP]),
+    "rsb_collect_prepare_on": (C.c_int, [_VP, _VP]),
     "rsb_collect_fence": (C.c_int, [_VP, _VP]),
     "rsb_submit_many": (C.c_int, [_VP, _SZ, _VP, _VP, _VP]),
     "rsb_collect_many": (C.c_int, [_VP, _SZ, _VP, _VP, _VP]),
@@ -346,8 +347,12 @@ class Channel:
         self._check(rc, "rsb_collect_begin")
         return out[:n.value]
 
-    def collect_prepare(self):
-        self._check(self.l.rsb_collect_prepare(self.h), "rsb_collect_prepare")
+    def collect_prepare(self, on_stream=None):
+        """rsb_collect_prepare; on_stream (a stream handle, 0 = the default stream): rsb_collect_prepare_on, the chain on that stream"""
+        if on_stream is None:
+            self._check(self.l.rsb_collect_prepare(self.h), "rsb_collect_prepare")
+        else:
+            self._check(self.l.rsb_collect_prepare_on(self.h, int(on_stream)), "rsb_collect_prepare_on")
 
     def collect_fence(self, stream: int = 0):
         self._check(self.l.rsb_collect_fence(self.h, stream), "rsb_collect_fence")

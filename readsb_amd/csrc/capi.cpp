@@ -124,12 +124,12 @@ int setup_device(rsb_ctx *c) {
         HIP_TRY(c, hipMalloc((void **)&b.d_block_means, c->nblocks_cap * 2 * sizeof(double)));
         for (hipEvent_t &ev : b.ev) HIP_TRY(c, hipEventCreate(&ev));
         for (hipEvent_t &ev : b.rev) HIP_TRY(c, hipEventCreate(&ev));
-        HIP_TRY(c, hipEventCreateWithFlags(&b.chain_done, hipEventDisableTiming));
     }
     HIP_TRY(c, hipStreamCreateWithFlags(&c->replay_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->reset_done, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->tables_ev, hipEventDisableTiming));
     for (void *&p : c->d_carry) HIP_TRY(c, hipMalloc(&p, kTrailing * 4));
     c->sort_temp_bytes = sort_temp_bytes(c->surv_item_cap);
     HIP_TRY(c, hipMalloc(&c->d_sort_temp, c->sort_temp_bytes));
@@ -263,6 +263,18 @@ int enqueue_readbacks(rsb_ctx *c, rsb_slot &b, const ReplayArgs &r, hipStream_t 
 // left in the batch's counters, and replay_finish checks what the host could not know beforehand).
 // direct_out (optional, RSB_EMIT_DIRECT=1): the caller's record buffer.  If the device can address it (pinned host memory), the
 // emit kernel writes the records there itself and no device -> host copy follows.
+// The first-add tables are worked on by one batch after the other, but not always on one stream (the context's own; ctx[0]'s for
+// rsb_collect_many; the caller's for rsb_collect_prepare_on): whoever touches them next on another stream waits on the device.
+int order_tables(rsb_ctx *c, hipStream_t s) {
+    if (c->tables_stream && c->tables_stream != s) HIP_TRY(c, hipStreamWaitEvent(s, c->tables_ev, 0));
+    return RSB_OK;
+}
+int tables_touched(rsb_ctx *c, hipStream_t s) {
+    HIP_TRY(c, hipEventRecord(c->tables_ev, s));
+    c->tables_stream = s;
+    return RSB_OK;
+}
+
 // the replay's arguments for the slot's pending batch (the tables t_cur / t_next are the caller's to set: the mirror may swap them)
 void fill_replay_args(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_device) {
     const BatchArgs &a = b.pending_args;
@@ -298,8 +310,10 @@ void fill_replay_args(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_d
 int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_device, hipStream_t s, rsb_message *direct_out = nullptr, size_t direct_cap = 0) {
     const BatchArgs &a = b.pending_args;
     int rc;
+    if ((rc = order_tables(c, s)) != RSB_OK) return rc;
     if (c->filter_dirty && (rc = mirror_filter(c, s)) != RSB_OK) return rc;
     fill_replay_args(c, b, n_items, count_on_device);
+    b.chain_on = s;
     ReplayArgs &r = b.chain_r;
     // A record copy that rsb_collect_begin left in flight reads the d_out of ITS slot; this chain writes this slot's.  The same
     // slot only on one-slot contexts (dc_filter, SC16Q11 table): begin(k), submit(k + 1), prepare(k + 1) -- the chain then waits
@@ -308,7 +322,6 @@ int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devi
     HIP_TRY(c, hipEventRecord(b.rev[1], s));
     if (r.nblocks == 0) {
         HIP_TRY(c, hipEventRecord(b.rev[2], s));
-        HIP_TRY(c, hipEventRecord(b.chain_done, s));
         return RSB_OK;
     }
     r.t_cur = c->d_first_add[c->first_cur];  // seeded with the optimistic "first added at" entries (k_replay_table_min<true>)
@@ -340,7 +353,6 @@ int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devi
     HIP_TRY(c, launch_replay_emit(a, r, s));
     if ((rc = enqueue_readbacks(c, b, r, s)) != RSB_OK) return rc;
     HIP_TRY(c, hipEventRecord(b.rev[2], s));
-    HIP_TRY(c, hipEventRecord(b.chain_done, s));  // (what rsb_collect_fence waits for: an event without timing)
     return RSB_OK;
 }
 
@@ -365,7 +377,11 @@ int replay_finish(rsb_ctx *c, rsb_slot &b, hipStream_t s, uint32_t cnt[kCntCount
             pin[0] = 0;
             HIP_TRY(c, hipMemcpyAsync(&pin[0], b.d_counters + kCntChanged, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         }
-        HIP_TRY(c, hipStreamSynchronize(s));
+        // (a chain on the caller's stream: whatever the caller queued behind it -- the next scan -- is not waited for)
+        if (it == 0 && b.chain_foreign)
+            HIP_TRY(c, hipEventSynchronize(b.rev[2]));
+        else
+            HIP_TRY(c, hipStreamSynchronize(s));
         const uint32_t changed = it == 0 ? pin[1 + kCntChanged] : pin[0];
         if (it == 0) {
             std::memcpy(cnt, pin + 1, kCntCount * sizeof(uint32_t));
@@ -476,8 +492,9 @@ int drop_enqueued_chain(rsb_ctx *c) {
     rsb_slot &nb = c->collect_slot();
     if (!nb.pending || !nb.chain_enqueued) return RSB_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    HIP_TRY(c, hipStreamSynchronize(c->replay_stream));
+    HIP_TRY(c, hipStreamSynchronize(nb.chain_foreign ? nb.chain_on : c->replay_stream));
     nb.chain_enqueued = false;
+    nb.chain_foreign = false;
     nb.pruned = false;  // the superset may have grown: the prune runs again at collect time (it rebuilds everything it writes)
     c->filter_dirty = true;
     c->tables_valid = false;  // the dropped round's seed entries are in the tables
@@ -579,6 +596,7 @@ void rsb_destroy(rsb_ctx *c) {
     if (c->addr_upload_done) (void)hipEventDestroy(c->addr_upload_done);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     if (c->reset_done) (void)hipEventDestroy(c->reset_done);
+    if (c->tables_ev) (void)hipEventDestroy(c->tables_ev);
     void *ptrs[] = {c->d_lut, c->d_radial, c->d_crc_bytes, c->d_sbs, c->d_syn_keys[0], c->d_syn_keys[1], c->d_syn_vals[0], c->d_syn_vals[1], c->d_sort_temp, c->d_surv_g, c->d_surv,
                     c->d_bitmap, c->d_summary, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
                     c->d_magbuf, c->d_sub_means, c->d_wave_times, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge, c->d_dec_in, c->d_decoded, c->d_addr_list};
@@ -590,7 +608,6 @@ void rsb_destroy(rsb_ctx *c) {
             if (ev) (void)hipEventDestroy(ev);
         for (hipEvent_t ev : b.rev)
             if (ev) (void)hipEventDestroy(ev);
-        if (b.chain_done) (void)hipEventDestroy(b.chain_done);
         if (b.h_pin) (void)hipHostFree(b.h_pin);
     }
     if (c->replay_stream) (void)hipStreamDestroy(c->replay_stream);
@@ -621,6 +638,7 @@ int rsb_reset(rsb_ctx *c) {
     for (rsb_slot &b : c->slots) {
         b.pending = false;
         b.chain_enqueued = false;
+        b.chain_foreign = false;
     }
     for (int &v : c->carry_valid) v = 0;
     c->finished = c->submit_finished = false;
@@ -794,15 +812,18 @@ static int enqueue_before_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, hipS
     b.scan_share = 1.0f;
     b.scan_timed = b.ac_timed = true;
     if (in_one_launch) return RSB_OK;
-    HIP_TRY(c, hipMemsetAsync(b.d_counters, 0, kCntAlloc * sizeof(uint32_t), s));
-    HIP_TRY(c, hipMemsetAsync(b.d_region_counts, 0, (size_t)a.n_regions * sizeof(uint32_t), s));
+    HIP_TRY(c, launch_submit_prepare(a, s));  // counters and region counts to zero, the next batch's overlap copied (a.carry_out): one launch
     HIP_TRY(c, hipEventRecord(b.ev[0], s));
     return RSB_OK;
 }
 
 static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s, bool in_one_launch = false);
 
-static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint64_t nsamples, hipStream_t s) {
+static int enqueue_batch(rsb_ctx *c, rsb_slot &b, const BatchArgs &a_in, uint64_t nsamples, hipStream_t s) {
+    BatchArgs a = a_in;
+    // the next batch's 326-sample overlap (sdr_ifile.c:199-201) leaves with the prepare kernel in front of the scan (with the DC block
+    // inside the kernels it is made behind the scan, as magnitudes: enqueue_after_scan)
+    if (!c->block_mode && nsamples && nsamples % c->block_len == 0 && !a.dc_local) a.carry_out = c->d_carry[(c->submitted + 1) % rsb_ctx::kCarries];
     int rc = enqueue_before_scan(c, b, a, s);
     if (rc != RSB_OK) return rc;
     if (c->run_modes) HIP_TRY(c, launch_scan(a, c->scan_grid, s));
@@ -818,7 +839,7 @@ static int enqueue_after_scan(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, uint6
     b.pruned_in_order = false;
     const bool ac_work = (c->run_ac || c->exact_stats) && nsamples;
     // (the one launch for many channels: no event per channel where nothing lies between it and the next one)
-    if (!in_one_launch || ac_work) HIP_TRY(c, hipEventRecord(b.ev[2], s));
+    if (ac_work) HIP_TRY(c, hipEventRecord(b.ev[2], s));
     else b.ac_timed = false;
     b.means_on_device = nullptr;
     if (ac_work) {
@@ -1065,6 +1086,7 @@ int CollectRun::replay() {
             if (rc != RSB_OK) return rc;
         }
         on_device = replay_finish(c, b, s, cnt);
+        (void)tables_touched(c, s);  // (the fold, or whatever an unfinished round left in the tables)
         if (on_device == -1000)
             on_device = 0;  // cnt[] says why: looked at below
         else if (on_device < 0)
@@ -1135,6 +1157,7 @@ int CollectRun::replay() {
             chain_ran = true;
             if (rc != RSB_OK) return rc;
             on_device = replay_finish(c, b, s, cnt, &direct_parts);
+            (void)tables_touched(c, s);
             if (on_device < 0) return on_device;
             if (!on_device) direct_parts = 0;  // (whatever the kernel wrote to the buffer, the host path rewrites it)
         }
@@ -1145,7 +1168,9 @@ int CollectRun::replay() {
         HIP_TRY(c, hipMemcpyAsync(&nsurv, b.d_counters + kCntSurvivors, sizeof(nsurv), hipMemcpyDeviceToHost, s));
     }
     if (!on_device || !chain_ran) HIP_TRY(c, hipEventRecord(b.rev[2], s));  // (the device replay's chain records it behind its emit kernel)
-    HIP_TRY(c, hipStreamSynchronize(s));
+    // (a chain on the caller's stream that replayed the batch on the device has been waited for by its event, and nothing the host needs
+    // has been enqueued since: the stream itself may hold the caller's next scan by now)
+    if (!(on_device && chain_ran && b.chain_foreign)) HIP_TRY(c, hipStreamSynchronize(s));
     if (!on_device && nsurv > c->surv_cap) {
         char buf[200];
         std::snprintf(buf, sizeof(buf), "device queue overflow: surviving offsets %u/%u (lower rsb_config.queue_div)", nsurv, c->surv_cap);
@@ -1315,6 +1340,7 @@ int CollectRun::host_list() {
 }
 
 int CollectRun::account(size_t *n_out) {
+    b.chain_foreign = false;
     rsb_stats &st = c->replay.stats();
     if (on_device && chain_ran && c->run_modes) {  // the kept items the replay worked on stay where they are until this slot is scanned again
         c->last_items_info = b.chain_r.info;
@@ -1381,7 +1407,8 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     // everything from here on runs on the context's own stream, behind this batch's scan and beside the next batch's
     // (rsb_collect_many: the channels' shared chain ran on one stream, and whatever is left to do for this channel follows it there)
-    hipStream_t s = c->chain_stream ? c->chain_stream : c->replay_stream;
+    const bool foreign = b.chain_enqueued && b.chain_foreign;  // rsb_collect_prepare_on: the chain is on the caller's stream, the rest follows it there
+    hipStream_t s = c->chain_stream ? c->chain_stream : (foreign ? b.chain_on : c->replay_stream);
     if (!c->chain_stream) c->own_stream_used = true;  // (work for the filter tables may be left on it when this call returns: the fold)
     HIP_TRY(c, hipStreamWaitEvent(s, b.ev[3], 0));
     if (!b.chain_enqueued) HIP_TRY(c, hipEventRecord(b.rev[0], s));  // (collect_ahead has recorded it otherwise)
@@ -1406,8 +1433,19 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
 
 extern "C" {
 
+static int collect_prepare_impl(rsb_ctx *c, hipStream_t s, bool foreign);
+
 int rsb_collect_prepare(rsb_ctx *c) {
     if (!c) return RSB_EINVAL;
+    return collect_prepare_impl(c, c->replay_stream, false);
+}
+
+int rsb_collect_prepare_on(rsb_ctx *c, void *stream) {
+    if (!c) return RSB_EINVAL;
+    return collect_prepare_impl(c, (hipStream_t)stream, true);
+}
+
+static int collect_prepare_impl(rsb_ctx *c, hipStream_t s, bool foreign) {
     if (!c->any_pending()) {
         c->err = "rsb_collect_prepare: nothing submitted";
         return RSB_ESTATE;
@@ -1415,7 +1453,7 @@ int rsb_collect_prepare(rsb_ctx *c) {
     rsb_slot &nb = c->collect_slot();
     if (nb.chain_enqueued || !chain_needs_no_host(c, nb)) return RSB_OK;  // (the second case: rsb_collect does it step by step)
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    hipStream_t s = c->replay_stream;
+    nb.chain_foreign = foreign;
     HIP_TRY(c, hipStreamWaitEvent(s, nb.ev[3], 0));
     HIP_TRY(c, hipEventRecord(nb.rev[0], s));
     if (!nb.pruned) {
@@ -1424,7 +1462,7 @@ int rsb_collect_prepare(rsb_ctx *c) {
     }
     c->sorted_buf = 0;
     const int rc = replay_enqueue(c, nb, kept_items_bound(c, nb), true, s);
-    if (rc != RSB_OK) nb.chain_enqueued = false;
+    if (rc != RSB_OK) nb.chain_enqueued = nb.chain_foreign = false;
     return rc;
 }
 
@@ -1437,7 +1475,7 @@ int rsb_collect_fence(rsb_ctx *c, void *stream) {
     rsb_slot &nb = c->collect_slot();
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     // behind the prepared chain's last kernel and readbacks; without a prepared chain, behind the batch's scan
-    HIP_TRY(c, hipStreamWaitEvent((hipStream_t)stream, nb.chain_enqueued ? nb.chain_done : nb.ev[3], 0));
+    HIP_TRY(c, hipStreamWaitEvent((hipStream_t)stream, nb.chain_enqueued ? nb.rev[2] : nb.ev[3], 0));
     return RSB_OK;
 }
 

@@ -29,7 +29,8 @@ struct rsb_slot {
     double *d_block_means = nullptr;  // SC16 / SC16Q11 with Mode A/C: the float converters' per-block means
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // scan start / end, prune end, Mode A/C end
     hipEvent_t rev[3] = {nullptr, nullptr, nullptr};          // collect side: sort start / end, replay end
-    hipEvent_t chain_done = nullptr;  // behind the enqueued chain's last operation (no timing: other streams wait for it on the device)
+    hipStream_t chain_on = nullptr;   // the stream the enqueued chain is on: the context's own, or -- rsb_collect_prepare_on -- the caller's
+    bool chain_foreign = false;
     // device replay of this batch (one set per slot: the chain of batch k + 1 is enqueued while batch k's records still leave)
     rsb_message *d_out = nullptr;     // the batch's message records
     uint32_t *d_blk_counts = nullptr, *d_blk_start = nullptr, *d_blk_base = nullptr;
@@ -190,6 +191,8 @@ struct rsb_ctx {
     hipEvent_t many_args_read[2] = {nullptr, nullptr};
     bool many_args_pending[2] = {false, false};
     unsigned many_calls = 0;
+    hipStream_t tables_stream = nullptr;    // the stream that last worked on the first-add tables (mirror, seed, fold), until a host wait covered it
+    hipEvent_t tables_ev = nullptr;         // ... and behind its last operation there: a chain on another stream waits for it
     bool own_stream_used = false;           // a collect of this channel alone has put work on replay_stream since rsb_collect_many last looked
     hipStream_t chain_stream = nullptr;     // set while rsb_collect_many collects this channel behind a chain shared with other channels
     rsb::ChainArgs *d_chain_args = nullptr, *h_chain_args = nullptr;  // rsb_collect_many: the channels' chain arguments (held by the first channel)

@@ -3440,8 +3440,12 @@ hipError_t launch_scan_many(int fmt, const BatchArgs *args_dev, uint32_t nbatche
 }
 
 // what rsb_submit's memsets and carry copy do, for every batch of a launch_scan_many at once (64 memsets and 32 copies otherwise)
-__global__ __launch_bounds__(kThreads) void k_submit_prepare_many(const BatchArgs *__restrict__ args) {
-    const BatchArgs &a = args[blockIdx.y];
+__device__ __forceinline__ void submit_prepare_body(const BatchArgs &a);
+__global__ __launch_bounds__(kThreads) void k_submit_prepare_many(const BatchArgs *__restrict__ args) { submit_prepare_body(args[blockIdx.y]); }
+// (one batch, arguments by value: rsb_submit's two fills and its carry copy as one launch -- three operations fewer in the queue between
+// the chain of the batch before and this batch's scan)
+__global__ __launch_bounds__(kThreads) void k_submit_prepare(const BatchArgs a) { submit_prepare_body(a); }
+__device__ __forceinline__ void submit_prepare_body(const BatchArgs &a) {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i < (uint32_t)kCntAlloc) a.counters[i] = 0;
     for (uint32_t r = i; r < a.n_regions; r += gridDim.x * kThreads) a.region_counts[r] = 0;
@@ -3451,6 +3455,14 @@ __global__ __launch_bounds__(kThreads) void k_submit_prepare_many(const BatchArg
         for (uint32_t k = i; k < halves; k += gridDim.x * kThreads) ((uint16_t *)a.carry_out)[k] = src[k];
     }
 }
+hipError_t launch_submit_prepare(const BatchArgs &a, hipStream_t s) {
+    unsigned gx = (a.n_regions + kThreads - 1) / kThreads;
+    if (gx < 1) gx = 1;
+    if (gx > 4) gx = 4;
+    hipLaunchKernelGGL(k_submit_prepare, dim3(gx), dim3(kThreads), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_submit_prepare_many(const BatchArgs *args_dev, uint32_t nbatches, uint32_t max_regions, hipStream_t s) {
     if (nbatches == 0) return hipSuccess;
     unsigned gx = (max_regions + kThreads - 1) / kThreads;

@@ -174,6 +174,7 @@ hipError_t launch_scan(const BatchArgs &a, int grid, hipStream_t s);
 // nbatches batches of one format in one launch: args_dev[i] built for groups_per_batch workgroups (n_regions = 16 x that), n = 0 allowed
 hipError_t launch_scan_many(int fmt, const BatchArgs *args_dev, uint32_t nbatches, uint32_t groups_per_batch, hipStream_t s);
 // in front of launch_scan_many: every batch's counters and region counts to zero and its carry_out filled, in one launch
+hipError_t launch_submit_prepare(const BatchArgs &a, hipStream_t s);  // one batch (a.carry_out set: its overlap for the next batch is copied as well)
 hipError_t launch_submit_prepare_many(const BatchArgs *args_dev, uint32_t nbatches, uint32_t max_regions, hipStream_t s);
 hipError_t launch_prune(const BatchArgs &a, hipStream_t s);
 hipError_t launch_prune_ordered(const BatchArgs &a, hipStream_t s);

@@ -962,6 +962,46 @@ def test_thirty_two_channels_share_one_chain(pessimistic, built, monkeypatch):
     assert sum(w.size for w in want) > 8000
 
 
+@pytest.mark.parametrize("pessimistic,modeac", [(False, False), (True, False), (False, True)])
+def test_chain_on_the_submit_stream(pessimistic, modeac, built, monkeypatch):
+    """rsb_collect_prepare_on: a batch's prune / replay / emit chain on the stream its scan was submitted on, the next batch's scan (of
+    another channel, and of the same channel) queued behind it before the collect -- which waits for the chain's event, not for the
+    stream.  Two channels taking turns as bench.py does, a stream of torch's; also with every batch going through further replay rounds
+    (RSB_PESSIMISTIC_START=1: those are enqueued behind the next scan) and with Mode A/C (its merge on the device likewise).  Against
+    the oracle; a filter change from outside drops the prepared chain."""
+    import torch
+    from readsb_amd.synth import Scenario
+
+    if pessimistic:
+        monkeypatch.setenv("RSB_PESSIMISTIC_START", "1")
+    nb = 2 * 131072
+    iqs = [generate(Scenario(7 * 131072 + 4000, seed=310 + k, frames_per_sec=3000 + 500 * k, modeac_per_sec=300 if modeac else 0)) for k in range(2)]
+    devs = [torch.from_numpy(x).cuda() for x in iqs]
+    st = torch.cuda.Stream()
+    stream = st.cuda_stream
+    torch.cuda.synchronize()
+    chans = [readsb_amd.Channel(fmt="UC8", fix_bits=1, mode_ac=modeac, max_batch_samples=nb) for _ in range(2)]
+    outs = [torch.empty((1 << 13) * 56, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE) for _ in range(2)]
+    cuts = list(range(0, iqs[0].shape[0], nb)) + [iqs[0].shape[0]]
+    work = [(k, b) for b in range(len(cuts) - 1) for k in range(2)]  # (channel, batch) in the order they are scanned
+    got = [[] for _ in range(2)]
+    sub = lambda k, b: chans[k].submit(devs[k].data_ptr() + 2 * cuts[b], cuts[b + 1] - cuts[b], stream)
+    sub(*work[0])
+    for i, (k, b) in enumerate(work):
+        chans[k].collect_prepare(on_stream=stream)
+        if i + 1 < len(work):
+            sub(*work[i + 1])           # behind the chain, before the collect
+        if i == 3:                      # a filter change while a chain is prepared: dropped, the batch is replayed at collect time
+            chans[k].filter_add(0xABCDEF)
+        part = chans[k].collect_begin(outs[k])
+        chans[k].collect_wait()
+        got[k].append(part.copy())
+    for k in range(2):
+        want, _ = Oracle(fmt="UC8", nfix=1, modeac=modeac).run_stream(iqs[k])
+        assert first_mismatch(want, np.concatenate(got[k]).view(REC_DTYPE)) is None, k
+        chans[k].close()
+
+
 def test_shared_chain_and_single_collects_in_turn(built):
     """channels collected through the shared chain (one stream for all), then each by itself (its own stream), then together again:
     the filter tables follow from one stream to the other"""
