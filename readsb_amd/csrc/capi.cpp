@@ -1086,7 +1086,8 @@ int CollectRun::replay() {
             if (rc != RSB_OK) return rc;
         }
         on_device = replay_finish(c, b, s, cnt);
-        (void)tables_touched(c, s);  // (the fold, or whatever an unfinished round left in the tables)
+        // (the fold, or whatever an unfinished round left in the tables; rsb_collect_many ends with a host wait for its shared stream instead)
+        if (!c->chain_stream) (void)tables_touched(c, s);
         if (on_device == -1000)
             on_device = 0;  // cnt[] says why: looked at below
         else if (on_device < 0)
@@ -1157,7 +1158,7 @@ int CollectRun::replay() {
             chain_ran = true;
             if (rc != RSB_OK) return rc;
             on_device = replay_finish(c, b, s, cnt, &direct_parts);
-            (void)tables_touched(c, s);
+            if (!c->chain_stream) (void)tables_touched(c, s);
             if (on_device < 0) return on_device;
             if (!on_device) direct_parts = 0;  // (whatever the kernel wrote to the buffer, the host path rewrites it)
         }
@@ -1409,7 +1410,6 @@ int collect_impl(rsb_ctx *c, rsb_message *out, size_t cap, size_t *n_out, WireRe
     // (rsb_collect_many: the channels' shared chain ran on one stream, and whatever is left to do for this channel follows it there)
     const bool foreign = b.chain_enqueued && b.chain_foreign;  // rsb_collect_prepare_on: the chain is on the caller's stream, the rest follows it there
     hipStream_t s = c->chain_stream ? c->chain_stream : (foreign ? b.chain_on : c->replay_stream);
-    if (!c->chain_stream) c->own_stream_used = true;  // (work for the filter tables may be left on it when this call returns: the fold)
     HIP_TRY(c, hipStreamWaitEvent(s, b.ev[3], 0));
     if (!b.chain_enqueued) HIP_TRY(c, hipEventRecord(b.rev[0], s));  // (collect_ahead has recorded it otherwise)
     if (c->run_modes && !b.pruned && !b.chain_enqueued) {  // against the superset as it is now (the caller may have widened it)
@@ -1677,12 +1677,10 @@ static int run_one_chain(rsb_ctx *const *ctx, size_t nch) {
     for (size_t i = 0; i < nch; ++i) {
         const int rc = rsb_collect_wait(ctx[i]);  // (a record copy left in flight reads the d_out this chain writes, on one-slot contexts)
         if (rc != RSB_OK) return rc;
-        // a channel collected by itself before has left its last kernels (the fold into its filter tables) on its own stream, which
-        // the shared stream knows nothing of
-        if (ctx[i] != c0 && ctx[i]->own_stream_used) {
-            HIP_TRY(ctx[i], hipStreamSynchronize(ctx[i]->replay_stream));
-            ctx[i]->own_stream_used = false;
-        }
+        // a channel collected by itself before has left its last kernels (the fold into its filter tables) on another stream -- its
+        // own, or the caller's -- which the shared stream knows nothing of: wait for them on the device
+        const int rc2 = order_tables(ctx[i], s);
+        if (rc2 != RSB_OK) return rc2;
     }
     if (nch > c0->chain_args_cap) {
         if (c0->d_chain_args) (void)hipFree(c0->d_chain_args);
@@ -1868,6 +1866,7 @@ static int collect_many_impl(rsb_ctx *const *ctx, size_t nch, rsb_message *const
         }
         // ... which that channel's own stream knows nothing of: wait for it here (rare)
         if (tail_on_shared_stream && hipStreamSynchronize(s) != hipSuccess && first == RSB_OK) first = RSB_ENODEV;
+        for (size_t i = 0; i < nch; ++i) ctx[i]->tables_stream = nullptr;  // (every table operation of this call has been waited for on the host)
         for (size_t i = 0; i < nch && (wait_for_copies || (first != RSB_OK && first != RSB_EOVERFLOW)); ++i) {
             rc = rsb_collect_wait(ctx[i]);
             if (rc != RSB_OK && first == RSB_OK) first = rc;
