@@ -304,7 +304,8 @@ def main() -> int:
     # contexts keep the converter and its one magnitude buffer: one step at a time
     dc_fused = args.dcfilter and not args.modeac and not os.environ.get("RSB_DC_UNFUSED")
     if args.chain_on_submit_stream < 0:
-        args.chain_on_submit_stream = 0 if args.modeac else 1
+        # (many channels: measured 2.88 against 2.55 ms -- the 32 record copies then start beside a running scan instead of on an idle chip)
+        args.chain_on_submit_stream = 0 if args.modeac or args.channels_per_gpu > 1 else 1
     if args.submit_ahead < 0:
         args.submit_ahead = 0  # (measured: the next step's scan takes every CU and starves this step's chain -- 4.7 instead of 4.1 ms with --dcfilter)
     overlap = args.steps_in_flight == 2 and C == 1 and nb == 1 and args.output == "records" and (not args.dcfilter or dc_fused)
@@ -408,12 +409,21 @@ def main() -> int:
             if k > 0:
                 for c in other:
                     c.collect_wait()               # step k - 1's records are in host memory
-            if k + 1 < count:
-                for c in other:
-                    c.reset()
-            views = readsb_amd.collect_many(mine, [bufs[k % 2][i * per:(i + 1) * per] for i in range(C)], wait=False)
-            if k + 1 < count:
-                readsb_amd.submit_many(other, ptrs, lens, stream)
+            if args.chain_on_submit_stream:
+                # the shared chain of this step on the submit stream, the next step's scans behind it, then the host's part of the collect
+                readsb_amd.collect_many_prepare(mine, stream)
+                if k + 1 < count:
+                    for c in other:
+                        c.reset()
+                    readsb_amd.submit_many(other, ptrs, lens, stream)
+                views = readsb_amd.collect_many(mine, [bufs[k % 2][i * per:(i + 1) * per] for i in range(C)], wait=False)
+            else:
+                if k + 1 < count:
+                    for c in other:
+                        c.reset()
+                views = readsb_amd.collect_many(mine, [bufs[k % 2][i * per:(i + 1) * per] for i in range(C)], wait=False)
+                if k + 1 < count:
+                    readsb_amd.submit_many(other, ptrs, lens, stream)
             if tm is not None:
                 acc = {key: 0.0 for key in keys}
                 acc["replay_on_device"] = 1
@@ -623,7 +633,7 @@ def main() -> int:
                        "samples_per_gpu": n, "segment_samples": seg_n, "format": args.format, "fix_bits": args.fix_bits,
                        "mode_ac": bool(args.modeac), "dc_filter": bool(args.dcfilter),
                        "batches_per_step": len(cuts) - 1, "batches_in_flight": min(args.in_flight, len(cuts) - 1), "scan_workgroups": scan_wgs or "all",
-                       "steps_in_flight": 2 if overlap or overlap_many else 1, **({"chain_on_submit_stream": bool(args.chain_on_submit_stream)} if overlap else {}),
+                       "steps_in_flight": 2 if overlap or overlap_many else 1, **({"chain_on_submit_stream": bool(args.chain_on_submit_stream)} if overlap or overlap_many else {}),
                        **({"ms_per_step_one_at_a_time": serial_ms} if serial_ms is not None else {}),
                        "channels": world * C, "channels_per_gpu": C, "messages_per_step": nmsgs, "survivors_per_step": st["survivors"],
                        "full_size_check": parity, "oracle_check": oracle_check, "ranks_with_checks_ok": checks_ok, "output": args.output,

@@ -271,6 +271,11 @@ int rsb_collect_prepare_on(rsb_ctx *ctx, void *stream);
 int rsb_submit_many(rsb_ctx *const *ctx, size_t nch, const void *const *iq_dev, const uint64_t *nsamples, void *stream);
 int rsb_collect_many(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, const size_t *cap, size_t *n_out);
 int rsb_collect_many_begin(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, const size_t *cap, size_t *n_out);
+/* rsb_collect_prepare_on for all channels at once: the shared chain (or, for channel sets it does not take, every channel's own chain)
+ * is enqueued on `stream` -- normally the one the batches were submitted on -- and the call returns; submit the next batches on the
+ * stream, then rsb_collect_many[_begin], which waits for the chain's event and hands out the lists.  The host's work per channel (filter
+ * bookkeeping, starting the record copies, resets, the next submit) then runs beside the next scans instead of between chain and scan. */
+int rsb_collect_many_prepare_on(rsb_ctx *const *ctx, size_t nch, void *stream);
 
 /* Device-side ordering without the host: work enqueued on `stream` after this call starts only when the chain that
  * rsb_collect_prepare put on the context's own stream has finished (without a prepared chain: when the batch's scan has).  For a

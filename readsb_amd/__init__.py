@@ -101,6 +101,7 @@ SYMBOLS = {
     "rsb_submit_many": (C.c_int, [_VP, _SZ, _VP, _VP, _VP]),
     "rsb_collect_many": (C.c_int, [_VP, _SZ, _VP, _VP, _VP]),
     "rsb_collect_many_begin": (C.c_int, [_VP, _SZ, _VP, _VP, _VP]),
+    "rsb_collect_many_prepare_on": (C.c_int, [_VP, _SZ, _VP]),
     "rsb_process": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_process_host": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
     "rsb_get_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
@@ -167,6 +168,15 @@ def submit_many(chans, dev_ptrs, nsamples, stream: int = 0):
     rc = chans[0].l.rsb_submit_many(ctx, n, iq, ns, stream)
     if rc != 0:
         raise RsbError(f"rsb_submit_many: {rc}")
+
+
+def collect_many_prepare(chans, stream: int = 0):
+    """rsb_collect_many_prepare_on: the channels' shared chain onto `stream` (the submit stream), without waiting"""
+    n = len(chans)
+    ctx = (_VP * n)(*[c.h for c in chans])
+    rc = chans[0].l.rsb_collect_many_prepare_on(ctx, n, int(stream))
+    if rc != 0:
+        raise RsbError(f"rsb_collect_many_prepare_on: {rc}")
 
 
 def collect_many(chans, outs, wait=True):

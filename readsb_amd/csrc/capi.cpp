@@ -1667,9 +1667,10 @@ static bool one_chain_possible(rsb_ctx *const *ctx, size_t nch) {
 
 // enqueues the shared chain and waits for it; afterwards every channel's slot looks as if its own chain had been enqueued and
 // had run (b.chain_enqueued, the readbacks in b.h_pin): rsb_collect_begin takes it from there, on the shared stream
-static int run_one_chain(rsb_ctx *const *ctx, size_t nch) {
+// (s: ctx[0]'s own stream, or -- foreign -- the caller's, rsb_collect_many_prepare_on; the wait and the hand-over of what came back are
+// finish_one_chain's)
+static int run_one_chain(rsb_ctx *const *ctx, size_t nch, hipStream_t s, bool foreign) {
     rsb_ctx *c0 = ctx[0];
-    hipStream_t s = c0->replay_stream;
     HIP_TRY(c0, hipSetDevice(c0->cfg.device));
     ChainDims d;
     std::memset(&d, 0, sizeof(d));
@@ -1808,7 +1809,30 @@ static int run_one_chain(rsb_ctx *const *ctx, size_t nch) {
         HIP_TRY(c0, hipEventRecord(b0.rev[1], s));
     }
     HIP_TRY(c0, hipEventRecord(b0.rev[2], s));
-    HIP_TRY(c0, hipStreamSynchronize(s));
+    for (size_t i = 0; i < nch; ++i) {
+        rsb_slot &b = ctx[i]->collect_slot();
+        b.chain_foreign = foreign;
+        b.chain_on = s;
+    }
+    c0->many_prepared = nch;
+    c0->many_stream = s;
+    c0->many_foreign = foreign;
+    c0->many_stride = stride;
+    c0->many_nblocks = d.max_nblocks;
+    return RSB_OK;
+}
+
+static int finish_one_chain(rsb_ctx *const *ctx, size_t nch) {
+    rsb_ctx *c0 = ctx[0];
+    const uint32_t stride = c0->many_stride;
+    ChainDims d;
+    d.max_nblocks = c0->many_nblocks;
+    c0->many_prepared = 0;
+    // (on the caller's stream: the chain's last event, not the stream -- it may hold the caller's next scans by now)
+    if (c0->many_foreign)
+        HIP_TRY(c0, hipEventSynchronize(c0->collect_slot().rev[2]));
+    else
+        HIP_TRY(c0, hipStreamSynchronize(c0->many_stream));
     for (size_t i = 0; i < nch && d.max_nblocks; ++i) {  // every channel's part to where replay_finish looks for it
         rsb_ctx *c = ctx[i];
         rsb_slot &b = c->collect_slot();
@@ -1828,6 +1852,20 @@ int rsb_collect_many(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, c
     return collect_many_impl(ctx, nch, out, cap, n_out, true);
 }
 
+int rsb_collect_many_prepare_on(rsb_ctx *const *ctx, size_t nch, void *stream) {
+    if (!ctx) return RSB_EINVAL;
+    for (size_t i = 0; i < nch; ++i)
+        if (!ctx[i]) return RSB_EINVAL;
+    if (nch && ctx[0]->many_prepared) return RSB_OK;
+    if (one_chain_possible(ctx, nch)) return run_one_chain(ctx, nch, (hipStream_t)stream, true);
+    int first = RSB_OK;
+    for (size_t i = 0; i < nch; ++i) {  // (channels the shared chain does not take: each one's own chain, on the same stream)
+        const int rc = ctx[i]->any_pending() ? rsb_collect_prepare_on(ctx[i], stream) : RSB_OK;
+        if (rc != RSB_OK && first == RSB_OK) first = rc;
+    }
+    return first;
+}
+
 int rsb_collect_many_begin(rsb_ctx *const *ctx, size_t nch, rsb_message *const *out, const size_t *cap, size_t *n_out) {
     return collect_many_impl(ctx, nch, out, cap, n_out, false);
 }
@@ -1837,14 +1875,17 @@ static int collect_many_impl(rsb_ctx *const *ctx, size_t nch, rsb_message *const
     for (size_t i = 0; i < nch; ++i)
         if (!ctx[i] || (!out[i] && cap[i])) return RSB_EINVAL;
     int first = RSB_OK;
-    if (one_chain_possible(ctx, nch)) {
-        int rc = run_one_chain(ctx, nch);
+    const bool prepared = ctx[0]->many_prepared == nch && nch > 0;  // rsb_collect_many_prepare_on has enqueued the shared chain
+    if (prepared || one_chain_possible(ctx, nch)) {
+        int rc = prepared ? RSB_OK : run_one_chain(ctx, nch, ctx[0]->replay_stream, false);
+        if (rc == RSB_OK) rc = finish_one_chain(ctx, nch);
         if (rc != RSB_OK) {
             // (nothing was collected: every channel's batch is prepared again from scratch by whoever collects it)
             for (size_t i = 0; i < nch; ++i) {
                 rsb_slot &b = ctx[i]->collect_slot();
-                (void)hipStreamSynchronize(ctx[0]->replay_stream);
+                (void)hipStreamSynchronize(ctx[0]->many_stream ? ctx[0]->many_stream : ctx[0]->replay_stream);
                 b.chain_enqueued = false;
+                b.chain_foreign = false;
                 b.pruned = false;
                 b.time_from = nullptr;
                 ctx[i]->filter_dirty = true;
@@ -1852,7 +1893,7 @@ static int collect_many_impl(rsb_ctx *const *ctx, size_t nch, rsb_message *const
             }
             return rc;
         }
-        hipStream_t s = ctx[0]->replay_stream;
+        hipStream_t s = ctx[0]->many_stream;
         bool tail_on_shared_stream = false;
         for (size_t i = 0; i < nch; ++i) {
             n_out[i] = 0;

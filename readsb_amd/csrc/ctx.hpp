@@ -193,6 +193,10 @@ struct rsb_ctx {
     unsigned many_calls = 0;
     hipStream_t tables_stream = nullptr;    // the stream that last worked on the first-add tables (mirror, seed, fold), until a host wait covered it
     hipEvent_t tables_ev = nullptr;         // ... and behind its last operation there: a chain on another stream waits for it
+    size_t many_prepared = 0;               // rsb_collect_many: channels whose shared chain is enqueued and not yet waited for (held by the first channel)
+    hipStream_t many_stream = nullptr;      // ... the stream it is on
+    bool many_foreign = false;              // ... which is the caller's (rsb_collect_many_prepare_on)
+    uint32_t many_stride = 0, many_nblocks = 0;
     hipStream_t chain_stream = nullptr;     // set while rsb_collect_many collects this channel behind a chain shared with other channels
     rsb::ChainArgs *d_chain_args = nullptr, *h_chain_args = nullptr;  // rsb_collect_many: the channels' chain arguments (held by the first channel)
     uint32_t *d_chain_back = nullptr, *h_chain_back = nullptr;        // ... and what comes back of every channel, gathered

@@ -1040,7 +1040,8 @@ def test_many_channels_copies_left_in_flight(built):
     iqs = [generate(Scenario_for(k)) for k in range(4)]
     devs = [torch.from_numpy(x).cuda() for x in iqs]
     lists = {}
-    for wait in (True, False):
+    stream = torch.cuda.current_stream().cuda_stream
+    for wait in (True, False, "prepared"):
         chans = [readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=nb) for _ in range(4)]
         outs = [[torch.empty((1 << 13) * 56, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE) for _ in range(4)] for _ in range(2)]
         got = [[] for _ in range(4)]
@@ -1048,14 +1049,21 @@ def test_many_channels_copies_left_in_flight(built):
         readsb_amd.submit_many(chans, [d.data_ptr() for d in devs], [cuts[1]] * 4)
         pending = None
         for b in range(len(cuts) - 1):
-            views = readsb_amd.collect_many(chans, outs[b % 2], wait=wait)
-            if b + 2 < len(cuts):
-                readsb_amd.submit_many(chans, [d.data_ptr() + 2 * cuts[b + 1] for d in devs], [cuts[b + 2] - cuts[b + 1]] * 4)
+            if wait == "prepared":
+                # rsb_collect_many_prepare_on: the shared chain on the submit stream, the next batches behind it, then the collect
+                readsb_amd.collect_many_prepare(chans, stream)
+                if b + 2 < len(cuts):
+                    readsb_amd.submit_many(chans, [d.data_ptr() + 2 * cuts[b + 1] for d in devs], [cuts[b + 2] - cuts[b + 1]] * 4, stream)
+                views = readsb_amd.collect_many(chans, outs[b % 2], wait=False)
+            else:
+                views = readsb_amd.collect_many(chans, outs[b % 2], wait=wait)
+                if b + 2 < len(cuts):
+                    readsb_amd.submit_many(chans, [d.data_ptr() + 2 * cuts[b + 1] for d in devs], [cuts[b + 2] - cuts[b + 1]] * 4)
             if pending is not None:
                 for k in range(4):
                     got[k].append(pending[k].copy())
                 pending = None
-            if not wait:
+            if wait is not True:
                 for c in chans:
                     c.collect_wait()
             pending = views
@@ -1067,7 +1075,7 @@ def test_many_channels_copies_left_in_flight(built):
     for k in range(4):
         want, _ = Oracle(fmt="UC8", nfix=1).run_stream(iqs[k])
         assert first_mismatch(want, lists[True][k].view(REC_DTYPE)) is None
-        assert lists[True][k].tobytes() == lists[False][k].tobytes()
+        assert lists[True][k].tobytes() == lists[False][k].tobytes() == lists["prepared"][k].tobytes()
 
 
 def test_dcfilter_inside_the_kernels_with_host_replay(built):
