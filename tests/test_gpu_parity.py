@@ -1002,6 +1002,36 @@ def test_chain_on_the_submit_stream(pessimistic, modeac, built, monkeypatch):
         chans[k].close()
 
 
+def test_chain_on_the_submit_stream_falls_back_to_the_host(built):
+    """rsb_collect_prepare_on with a filter close to its capacity: the prepared chain declines the batch at collect time (the host
+    replay keeps the reference's table itself), and what that needs from the device is enqueued on the caller's stream behind the
+    next batch's scan, which was submitted in between -- late, but the lists are the oracle's"""
+    import torch
+
+    sc, kw = SCENARIOS["cfg1_df11_df17"]
+    iq = generate(sc).reshape(-1, 2)
+    adds = _addresses(2040, 2)
+    orc = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=kw["modeac"])
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], mode_ac=kw["modeac"], max_batch_samples=1 << 23)
+    for a in adds:
+        orc.filter_add(a)
+        ch.filter_add(a)
+    want, _ = orc.run_stream(iq, reset=False)
+    dev = torch.from_numpy(np.ascontiguousarray(iq)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    cut = 8 * 131072
+    out = torch.empty((1 << 14) * 56, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE)
+    ch.submit(dev.data_ptr(), cut, stream)
+    ch.collect_prepare(on_stream=stream)
+    ch.submit(dev.data_ptr() + 2 * cut, iq.shape[0] - cut, stream)
+    parts = [ch.collect(out=out).copy()]
+    assert ch.timing()["replay_on_device"] == 0
+    ch.collect_prepare(on_stream=stream)
+    parts.append(ch.collect(out=out).copy())
+    ch.close()
+    assert first_mismatch(want, np.concatenate(parts).view(REC_DTYPE)) is None
+
+
 def test_shared_chain_and_single_collects_in_turn(built):
     """channels collected through the shared chain (one stream for all), then each by itself (its own stream), then together again:
     the filter tables follow from one stream to the other"""
