@@ -119,7 +119,11 @@ int setup_device(rsb_ctx *c) {
             HIP_TRY(c, hipMalloc((void **)&b.d_sinfo[w], (size_t)c->surv_item_cap * sizeof(uint32_t)));
         }
         HIP_TRY(c, hipMalloc((void **)&b.d_ac, (size_t)c->ac_cap * sizeof(AcCand)));
-        HIP_TRY(c, hipMalloc((void **)&b.d_counters, kCntAlloc * sizeof(uint32_t)));
+        // counters, the device replay's per-block message counts and the batch's new filter members lie in ONE block: what the host
+        // wants to see of a replayed batch crosses PCIe in one copy (three before)
+        HIP_TRY(c, hipMalloc((void **)&b.d_counters, (c->back_adders() + 2 * (size_t)rsb_ctx::kNewAddersCap) * sizeof(uint32_t)));
+        b.d_blk_counts = b.d_counters + c->back_blk();
+        b.d_new_adders = (uint2 *)(b.d_counters + c->back_adders());
         HIP_TRY(c, hipMalloc((void **)&b.d_block_sums, c->nblocks_cap * 2 * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&b.d_block_means, c->nblocks_cap * 2 * sizeof(double)));
         for (hipEvent_t &ev : b.ev) HIP_TRY(c, hipEventCreate(&ev));
@@ -163,11 +167,9 @@ int setup_device(rsb_ctx *c) {
         for (int k = 0; k < c->nslots; ++k) {
             rsb_slot &b = c->slots[k];
             HIP_TRY(c, hipMalloc((void **)&b.d_out, (size_t)c->out_cap * sizeof(rsb_message)));
-            HIP_TRY(c, hipMalloc((void **)&b.d_blk_counts, c->nblocks_cap * sizeof(uint32_t)));
             HIP_TRY(c, hipMalloc((void **)&b.d_blk_start, (c->nblocks_cap + 1) * sizeof(uint32_t)));
             HIP_TRY(c, hipMalloc((void **)&b.d_blk_base, (c->nblocks_cap + 1) * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc((void **)&b.d_new_adders, rsb_ctx::kNewAddersCap * sizeof(uint2)));
-            HIP_TRY(c, hipHostMalloc((void **)&b.h_pin, (1 + kCntCount + c->nblocks_cap + 2 * rsb_ctx::kPinAdders) * sizeof(uint32_t), hipHostMallocDefault));
+            HIP_TRY(c, hipHostMalloc((void **)&b.h_pin, (1 + c->back_adders() + 2 * rsb_ctx::kPinAdders) * sizeof(uint32_t), hipHostMallocDefault));
         }
         HIP_TRY(c, hipMalloc((void **)&c->d_addr_upload, 8 * IcaoFilter::kSlots * sizeof(uint32_t)));  // 2 x kSlots members, up to 6 x kSlots stale entries
         HIP_TRY(c, hipHostMalloc((void **)&c->h_addr_upload, 8 * IcaoFilter::kSlots * sizeof(uint32_t), hipHostMallocDefault));
@@ -263,9 +265,8 @@ int enqueue_prune(rsb_ctx *c, rsb_slot &b, const BatchArgs &a, hipStream_t s) {
 // the readbacks of one replay round's results into the slot's pinned block: [changed | counters | block counts | first new adders]
 int enqueue_readbacks(rsb_ctx *c, rsb_slot &b, const ReplayArgs &r, hipStream_t s) {
     uint32_t *pin = b.h_pin;
-    HIP_TRY(c, hipMemcpyAsync(pin + 1, b.d_counters, kCntCount * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(pin + 1 + kCntCount, b.d_blk_counts, r.nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(pin + 1 + kCntCount + c->nblocks_cap, b.d_new_adders, rsb_ctx::kPinAdders * sizeof(uint2), hipMemcpyDeviceToHost, s));
+    (void)r;
+    HIP_TRY(c, hipMemcpyAsync(pin + 1, b.d_counters, (c->back_adders() + 2 * rsb_ctx::kPinAdders) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return RSB_OK;
 }
 
@@ -397,7 +398,7 @@ int replay_finish(rsb_ctx *c, rsb_slot &b, hipStream_t s, uint32_t cnt[kCntCount
         const uint32_t changed = it == 0 ? pin[1 + kCntChanged] : pin[0];
         if (it == 0) {
             std::memcpy(cnt, pin + 1, kCntCount * sizeof(uint32_t));
-            std::memcpy(c->h_blk_counts.data(), pin + 1 + kCntCount, r.nblocks * sizeof(uint32_t));
+            std::memcpy(c->h_blk_counts.data(), pin + 1 + c->back_blk(), r.nblocks * sizeof(uint32_t));
             if (b.chain_count_on_device) {
                 // now the host sees what the prune left: anything the kernels' clamps papered over ends the batch here
                 if (cnt[kCntOverflow] || cnt[kCntSurvItems] > c->surv_item_cap || cnt[kCntItems] != 0) {
@@ -431,7 +432,7 @@ int replay_finish(rsb_ctx *c, rsb_slot &b, hipStream_t s, uint32_t cnt[kCntCount
         if ((rc = enqueue_readbacks(c, b, r, s)) != RSB_OK) return rc;
         HIP_TRY(c, hipStreamSynchronize(s));
         std::memcpy(cnt, pin + 1, kCntCount * sizeof(uint32_t));
-        std::memcpy(c->h_blk_counts.data(), pin + 1 + kCntCount, r.nblocks * sizeof(uint32_t));
+        std::memcpy(c->h_blk_counts.data(), pin + 1 + c->back_blk(), r.nblocks * sizeof(uint32_t));
     }
     // the batch's new members become "in the filter before the next batch" (asynchronous; a chain for many channels has done it
     // on the device for the channels whose first round was the fixed point)
@@ -450,7 +451,7 @@ int replay_finish(rsb_ctx *c, rsb_slot &b, hipStream_t s, uint32_t cnt[kCntCount
     if (nnew) {
         c->h_new_adders.resize(nnew);
         if (nnew <= rsb_ctx::kPinAdders)  // came along with the counters
-            std::memcpy(c->h_new_adders.data(), pin + 1 + kCntCount + c->nblocks_cap, nnew * sizeof(uint2));
+            std::memcpy(c->h_new_adders.data(), pin + 1 + c->back_adders(), nnew * sizeof(uint2));
         else
             HIP_TRY(c, hipMemcpy(c->h_new_adders.data(), b.d_new_adders, nnew * sizeof(uint2), hipMemcpyDeviceToHost));
         std::sort(c->h_new_adders.begin(), c->h_new_adders.end(), [](const uint2 &x, const uint2 &y) { return x.x < y.x; });
@@ -613,7 +614,7 @@ void rsb_destroy(rsb_ctx *c) {
                     c->d_bitmap, c->d_summary, c->d_stage, c->d_mag, c->d_sums, c->d_first_add[0], c->d_first_add[1], c->d_addr_upload, c->d_means,
                     c->d_magbuf, c->d_sub_means, c->d_wave_times, c->d_dc_tile_sums, c->d_dc_tile_start, c->d_dc_state, c->d_wire_off, c->d_wire_out, c->d_merge, c->d_dec_in, c->d_decoded, c->d_addr_list};
     for (rsb_slot &b : c->slots) {
-        void *sp[] = {b.d_out, b.d_blk_counts, b.d_blk_start, b.d_blk_base, b.d_new_adders, b.d_items, b.d_region_counts, b.d_region_kept, b.d_region_masks, b.d_chunk_dir, b.d_chunk_kept, b.d_chunk_group, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
+        void *sp[] = {b.d_out, b.d_blk_start, b.d_blk_base, b.d_items, b.d_region_counts, b.d_region_kept, b.d_region_masks, b.d_chunk_dir, b.d_chunk_kept, b.d_chunk_group, b.d_skeys[0], b.d_skeys[1], b.d_sinfo[0], b.d_sinfo[1], b.d_ac, b.d_counters, b.d_block_sums, b.d_block_means};
         for (void *p : sp)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : b.ev)
@@ -1851,9 +1852,9 @@ static int finish_one_chain(rsb_ctx *const *ctx, size_t nch) {
         const uint32_t *src = c0->h_chain_back + (size_t)i * stride;
         const uint32_t nblk = b.chain_r.nblocks;
         std::memcpy(b.h_pin, src, (1 + kCntCount) * sizeof(uint32_t));
-        std::memcpy(b.h_pin + 1 + kCntCount, src + 1 + kCntCount, nblk * sizeof(uint32_t));
+        std::memcpy(b.h_pin + 1 + c->back_blk(), src + 1 + kCntCount, nblk * sizeof(uint32_t));
         const uint32_t nadd = std::min<uint32_t>(src[1 + kCntNewAdders], rsb_ctx::kPinAdders);
-        std::memcpy(b.h_pin + 1 + kCntCount + c->nblocks_cap, src + 1 + kCntCount + d.max_nblocks, (size_t)nadd * sizeof(uint2));
+        std::memcpy(b.h_pin + 1 + c->back_adders(), src + 1 + kCntCount + d.max_nblocks, (size_t)nadd * sizeof(uint2));
     }
     return RSB_OK;
 }

@@ -94,6 +94,9 @@ struct rsb_ctx {
     uint64_t *d_wave_times = nullptr;  // RSB_WAVE_TIMES=<file>: the scan wavefronts' start / end stamps of the last collected batch go there
     uint32_t *d_bitmap = nullptr;
     size_t nblocks_cap = 0;
+    // a slot's block of [counters (kCntAlloc) | messages per block (nblocks_cap, padded to an even count) | new filter members]: word offsets
+    size_t back_blk() const { return rsb::kCntAlloc; }
+    size_t back_adders() const { return rsb::kCntAlloc + ((nblocks_cap + 1) & ~(size_t)1); }
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
     uint16_t *d_mag = nullptr;  // drop-in block path
