@@ -360,9 +360,8 @@ int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devi
     // The first round is followed at once by the list and the records (the optimistic start is nearly always the fixed
     // point): one wait for "did the table move" and the counters together.  If it did move, those records are discarded,
     // the iteration goes on and they are written again.
-    HIP_TRY(c, launch_replay_iteration(a, r, s));
-    // ("did the table move" comes back with the counters: nothing behind k_replay_compare touches that word)
-    HIP_TRY(c, launch_replay_select(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
+    // ("did the table move" is the list kernel's answer and comes back with the counters)
+    HIP_TRY(c, launch_replay_first_round(a, r, s));
     HIP_TRY(c, launch_replay_emit(a, r, s));
     if ((rc = enqueue_readbacks(c, b, r, s)) != RSB_OK) return rc;
     HIP_TRY(c, hipEventRecord(b.rev[2], s));
@@ -415,7 +414,9 @@ int replay_finish(rsb_ctx *c, rsb_slot &b, hipStream_t s, uint32_t cnt[kCntCount
             converged = true;
             emitted = it == 0;
         } else {
-            // the table this walk produced becomes the current one; the other goes back to "before this batch"
+            // the table this walk produced becomes the current one (a chain's first round has not built it: now); the other goes
+            // back to "before this batch"
+            if (it == 0) HIP_TRY(c, launch_replay_next_table(r, s));
             c->first_cur ^= 1;
             HIP_TRY(c, launch_replay_reset(a, r, c->d_first_add[c->first_cur ^ 1], s));
         }

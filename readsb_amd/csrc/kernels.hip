@@ -1523,7 +1523,10 @@ __device__ __forceinline__ bool prune_keeps(const BatchArgs &a, const ItemRec &r
 // One workgroup per region.  Pass 1 decides every item (one 64-bit keep mask per 64 items, several item loads and set lookups in
 // flight per wavefront) and counts; a small kernel turns the regions' counts into offsets; pass 2 reads the masks and moves only the
 // kept items (6 % on the benchmark's traffic: 13 M items per Gsample are decided, 0.8 M move).
-constexpr int kPruneUnroll = 4;
+#ifndef RSB_PRUNE_UNROLL
+#define RSB_PRUNE_UNROLL 4
+#endif
+constexpr int kPruneUnroll = RSB_PRUNE_UNROLL;
 
 __device__ __forceinline__ void prune_count_body(const BatchArgs &a) {
     if (blockIdx.x >= a.n_regions) return;  // (a launch for several batches: the grid is the largest batch's)
@@ -1792,9 +1795,16 @@ __device__ __forceinline__ void replay_bounds_body(const ReplayArgs &r) {
 // that offset's best phase by strict '>' (demod_2400.c:290-301; at most five items, one per trial phase) and asks whether
 // decodeModesMessage would take it.  cand[i] = 0, or for such an offset: (best score + 1) | best item's distance << 16 |
 // (112-bit frame) << 20.  Fully parallel: the sequential part is left to k_replay_walk.
+// Every thread scores ITS item (key, info, then the table entry: two round trips to memory) and leaves the result in LDS, where the
+// offset's first thread reads its up to four followers; the workgroup's last offsets reach into the next workgroup's items, which
+// four threads score as well.  (One thread walking the five items by itself was fifteen dependent round trips: 41 us per Gsample.)
+#ifndef RSB_SCORE_SERIAL
+#define RSB_SCORE_SERIAL 0
+#endif
 __device__ __forceinline__ void replay_score_body(const ReplayArgs &r) {
     const uint32_t n_items = items_of(r);
     if (blockIdx.x == 0 && threadIdx.x == 0 && r.counters) r.counters[kCntChanged] = 0;  // (k_replay_compare of this round raises it)
+#if RSB_SCORE_SERIAL
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_items; i += gridDim.x * kThreads) {
         r.acc[i] = 0;
         const uint32_t g = (uint32_t)(r.keys[i] >> 3);
@@ -1823,6 +1833,67 @@ __device__ __forceinline__ void replay_score_body(const ReplayArgs &r) {
         }
         r.cand[i] = out;
     }
+#else
+    // per item in LDS: its offset, and (score + 4) | takes << 12 | long << 13, 0 for a marker item (score -3 .. 1800: never 0 otherwise)
+    __shared__ uint32_t s_g[kThreads + 4], s_w[kThreads + 4];
+    const uint32_t t = threadIdx.x;
+    for (uint32_t base = blockIdx.x * kThreads; base < n_items; base += gridDim.x * kThreads) {  // (uniform over the workgroup)
+        const uint32_t i = base + t, j = base + kThreads + t;  // j: the four items behind the workgroup's (threads 0-3)
+        const bool own = i < n_items, tail = t < 4 && j < n_items;
+        uint64_t key = 0, key_t = 0, key_before = ~0ull;
+        uint32_t info = 0, info_t = 0;
+        if (own) {
+            key = r.keys[i];
+            info = r.info[i];
+        }
+        if (tail) {
+            key_t = r.keys[j];
+            info_t = r.info[j];
+        }
+        if (t == 0 && base) key_before = r.keys[base - 1];
+        const uint32_t g = (uint32_t)(key >> 3), g_t = (uint32_t)(key_t >> 3);
+        const bool live = own && item_combo(info) != kComboMarker, live_t = tail && item_combo(info_t) != kComboMarker;
+        uint32_t first = kNever, first_t = kNever;
+        if (live) first = r.t_cur[item_value(info)];
+        if (live_t) first_t = r.t_cur[item_value(info_t)];
+        auto word = [](uint32_t inf, uint32_t at, uint32_t first_add) {
+            const uint32_t combo = item_combo(inf);
+            const bool member = first_add <= at;  // added by a message at an earlier offset
+            return (uint32_t)(combo_score(combo, member) + 4) | (combo_decodes(combo, member) ? 1u << 12 : 0u) | (combo_is_short(combo) ? 0u : 1u << 13);
+        };
+        if (own) r.acc[i] = 0;
+        s_g[t] = own ? g : kNever;
+        s_w[t] = live ? word(info, g, first) : 0u;
+        if (t < 4) {
+            s_g[kThreads + t] = tail ? g_t : kNever;
+            s_w[kThreads + t] = live_t ? word(info_t, g_t, first_t) : 0u;
+        }
+        __syncthreads();
+        if (own) {
+            uint32_t out = 0;
+            const bool starts = t ? s_g[t - 1] != g : (base == 0 || (uint32_t)(key_before >> 3) != g);
+            if (starts) {
+                int best = -3;
+                uint32_t best_off = 0, best_w = 0;
+#pragma unroll
+                for (uint32_t d = 0; d < 5; ++d) {
+                    if (i + d >= n_items || s_g[t + d] != g) break;  // (d == 0: the item itself)
+                    const uint32_t w = s_w[t + d];
+                    if (w == 0) continue;
+                    const int sc = (int)(w & 0xfffu) - 4;
+                    if (sc > best) {
+                        best = sc;
+                        best_off = d;
+                        best_w = w;
+                    }
+                }
+                if (best >= 0 && (best_w & (1u << 12))) out = ((uint32_t)best + 1u) | (best_off << 16) | ((best_w >> 13) << 20);
+            }
+            r.cand[i] = out;
+        }
+        __syncthreads();
+    }
+#endif
 }
 
 // One wavefront per 131072-sample block (one demodulate2400 call): the offsets that could be accepted, 64 items at a
@@ -1910,14 +1981,32 @@ __device__ __forceinline__ void replay_blkbase_body(const ReplayArgs &r) {
 //         over the offsets: what happens at offset g depends only on entries below g -- so the start affects the rounds only);
 //   else: the items the walk accepted, into the next table.
 #ifndef RSB_MIN_ITEMS
-#define RSB_MIN_ITEMS 2048  // (8192: 100 workgroups per Gsample of the benchmark traffic; 2048 measured 20 us faster over the two passes, 1024 no better)
+#define RSB_MIN_ITEMS 8192  // eight per thread of a 1024-thread workgroup.  Where the time goes (ablations, 0.8 M items, 40 new aircraft, per pass):
+                            // launch + loads 5 us, the LDS table 8 us, the global atomicMin 16 us -- 400 workgroups of 256 threads each
+                            // sent one per aircraft, and same-address atomics are served one after the other at the memory side
+                            // (~40 ns).  A quarter of the workgroups, four times the threads: 28 -> 21.5 us.  LDS atomics are not it
+                            // (plain reads in front of them: no change); nor are idle workgroups of the oversized grid.
 #endif
-constexpr int kMinSlots = 2048, kMinItemsPerGroup = RSB_MIN_ITEMS;
+#ifndef RSB_MIN_BATCH_ITEMS
+#define RSB_MIN_BATCH_ITEMS 1  // a thread's items loaded together: -3 us per pass (the same for the flush of the LDS table: +17 us, not kept)
+#endif
+#ifndef RSB_MIN_PLAIN_READS
+#define RSB_MIN_PLAIN_READS 1
+#endif
+#ifndef RSB_MIN_THREADS
+#define RSB_MIN_THREADS 1024
+#endif
+#ifndef RSB_MIN_SLOTS
+#define RSB_MIN_SLOTS 4096
+#endif
+constexpr int kMinSlots = RSB_MIN_SLOTS, kMinThreads = RSB_MIN_THREADS, kMinItemsPerGroup = RSB_MIN_ITEMS;
 template <bool SEED>
 __device__ __forceinline__ void replay_table_min_body(const ReplayArgs &r) {
     __shared__ uint32_t key[kMinSlots], val[kMinSlots];
     uint32_t *table = SEED ? r.t_cur : r.t_next;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kMinSlots; i += kThreads) {
+    // (the grid is sized from the host's bound on the kept items, ten times the count on ordinary traffic: most workgroups have no run)
+    if (blockIdx.x * (uint32_t)kMinItemsPerGroup >= items_of(r)) return;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kMinSlots; i += kMinThreads) {
         key[i] = kNever;
         val[i] = kNever;
     }
@@ -1925,12 +2014,48 @@ __device__ __forceinline__ void replay_table_min_body(const ReplayArgs &r) {
     const uint32_t n_items = items_of(r);
     for (uint32_t lo = blockIdx.x * (uint32_t)kMinItemsPerGroup; lo < n_items; lo += gridDim.x * (uint32_t)kMinItemsPerGroup) {  // (one run per workgroup when the host's bound holds)
         const uint32_t hi = min(n_items, lo + (uint32_t)kMinItemsPerGroup);
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+#if RSB_MIN_BATCH_ITEMS
+        // (a thread's items are all loaded before the first of them goes to the LDS table: one round trip to memory instead of one per item)
+        constexpr int kPer = kMinItemsPerGroup / kMinThreads;
+        static_assert(kMinItemsPerGroup % kMinThreads == 0 && kMinSlots % kMinThreads == 0, "whole rounds of the workgroup");
+        uint32_t info[kPer], g1[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const uint32_t i = lo + threadIdx.x + (uint32_t)k * kMinThreads;
+            info[k] = kDeadItem;
+            g1[k] = 0;
+            if (i < hi) {
+                const uint32_t inf = r.info[i], acc = SEED ? 1u : (uint32_t)r.acc[i];
+                g1[k] = (uint32_t)(r.keys[i] >> 3) + 1;
+                if (acc != 0 && combo_adds(item_combo(inf))) info[k] = inf;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            if (info[k] == kDeadItem) continue;
+            const uint32_t v = item_value(info[k]);
+            uint32_t h = ((v * 0x9E3779B1u) >> 16) & (kMinSlots - 1);
+            bool placed = false;
+            for (int probe = 0; probe < 16 && !placed; ++probe) {
+                // (plain reads first: a slot's key never changes once set, its value only falls -- a few dozen aircraft share a
+                // run's 2048 items, and an LDS atomic takes its lanes one by one)
+                uint32_t q = __atomic_load_n(&key[h], __ATOMIC_RELAXED);
+                if (RSB_MIN_PLAIN_READS == 0 || q == kNever) q = atomicCAS(&key[h], kNever, v);
+                if (q == kNever || q == v) {
+                    if (RSB_MIN_PLAIN_READS == 0 || __atomic_load_n(&val[h], __ATOMIC_RELAXED) > g1[k]) atomicMin(&val[h], g1[k]);
+                    placed = true;
+                }
+                h = (h + 1) & (kMinSlots - 1);
+            }
+            if (!placed && table[v] > g1[k]) atomicMin(&table[v], g1[k]);  // (a run with more distinct addresses than the table holds)
+        }
+#else
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += kMinThreads) {
             if (!SEED && r.acc[i] == 0) continue;
             const uint32_t info = r.info[i];
             if (!combo_adds(item_combo(info))) continue;
             const uint32_t v = item_value(info), g1 = (uint32_t)(r.keys[i] >> 3) + 1;
-            uint32_t h = (v * 0x9E3779B1u) >> 21;
+            uint32_t h = ((v * 0x9E3779B1u) >> 16) & (kMinSlots - 1);
             bool placed = false;
             for (int probe = 0; probe < 16 && !placed; ++probe) {
                 const uint32_t k = atomicCAS(&key[h], kNever, v);
@@ -1942,8 +2067,9 @@ __device__ __forceinline__ void replay_table_min_body(const ReplayArgs &r) {
             }
             if (!placed && table[v] > g1) atomicMin(&table[v], g1);  // (a run with more distinct addresses than the table holds)
         }
+#endif
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < (uint32_t)kMinSlots; i += kThreads) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kMinSlots; i += kMinThreads) {
             const uint32_t v = key[i];
             if (v != kNever && table[v] > val[i]) atomicMin(&table[v], val[i]);
             key[i] = kNever;
@@ -1974,21 +2100,49 @@ __global__ __launch_bounds__(kThreads) void k_replay_reset(const ReplayArgs r, u
         if (table[v] != 0) table[v] = kNever;  // 0 = known before this batch: stays
     }
 }
+// message number -> item for the record kernel, and the batch's new filter members.
+// CHECK (the first round of a chain): also "did the table move", without the next table.  t_next[v] would be the smallest offset + 1
+// over the ACCEPTED items that add v; it equals t_cur[v] = c for every v iff no accepted item of v lies below c and -- where c names an
+// item of this batch (neither 0 = known before nor kNever) -- the item at c is accepted (or a sibling at the same offset that adds
+// the same address: the phases of one offset are neighbours in the list).  That saves the chain k_replay_table_min<false> and
+// k_replay_compare; only a batch whose first round was not the fixed point builds the next table (launch_replay_next_table).
+template <bool CHECK>
 __device__ __forceinline__ void replay_list_body(const ReplayArgs &r, uint32_t *counters) {
     const uint32_t n_items = items_of(r);
+    bool moved = false;
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_items; i += gridDim.x * kThreads) {
-        if (r.acc[i] == 0) continue;
-        const uint32_t info = r.info[i], g = (uint32_t)(r.keys[i] >> 3);
-        // message number -> item (k_replay_emit works message by message): accepted messages before the item's block + its rank there
-        const uint32_t place = r.blk_base[g / r.block_len] + r.acc_rank[i];
-        if (place < n_items) r.acc_idx[place] = i;
-        if (!combo_adds(item_combo(info))) continue;
-        const uint32_t v = item_value(info), g1 = g + 1;
-        if (r.t_cur[v] == g1) {
-            const uint32_t slot = atomicAdd(&counters[kCntNewAdders], 1u);
-            if (slot < r.new_adders_cap) r.new_adders[slot] = make_uint2(g1, v);
+        const bool accepted = r.acc[i] != 0;
+        if (!CHECK && !accepted) continue;
+        const uint32_t info = r.info[i];
+        const bool adds = combo_adds(item_combo(info));
+        if (!accepted && !adds) continue;
+        const uint32_t g = (uint32_t)(r.keys[i] >> 3);
+        if (accepted) {
+            // accepted messages before the item's block + its rank there
+            const uint32_t place = r.blk_base[g / r.block_len] + r.acc_rank[i];
+            if (place < n_items) r.acc_idx[place] = i;
+        }
+        if (!adds) continue;
+        const uint32_t v = item_value(info), g1 = g + 1, c = r.t_cur[v];
+        if (accepted) {
+            if (c == g1) {
+                const uint32_t slot = atomicAdd(&counters[kCntNewAdders], 1u);
+                if (slot < r.new_adders_cap) r.new_adders[slot] = make_uint2(g1, v);
+            } else if (CHECK && g1 < c) {
+                moved = true;
+            }
+        } else if (CHECK && c == g1) {
+            bool sibling = false;
+            for (int d = -4; d <= 4; ++d) {
+                const int64_t j = (int64_t)i + d;
+                if (d == 0 || j < 0 || j >= (int64_t)n_items || (uint32_t)(r.keys[j] >> 3) != g || r.acc[j] == 0) continue;
+                const uint32_t other = r.info[j];
+                sibling |= combo_adds(item_combo(other)) && item_value(other) == v;
+            }
+            moved |= !sibling;
         }
     }
+    if (CHECK && moved) counters[kCntChanged] = 1;
 }
 __device__ __forceinline__ void replay_fold_body(const ReplayArgs &r) {
     const uint32_t n_items = items_of(r);
@@ -2405,9 +2559,10 @@ __global__ __launch_bounds__(kThreads) void k_replay_score(const ReplayArgs r) {
 __global__ __launch_bounds__(kThreads) void k_replay_walk(const ReplayArgs r) { replay_walk_body(r); }
 __global__ __launch_bounds__(1024) void k_replay_blkbase(const ReplayArgs r) { replay_blkbase_body(r); }
 template <bool SEED>
-__global__ __launch_bounds__(kThreads) void k_replay_table_min(const ReplayArgs r) { replay_table_min_body<SEED>(r); }
+__global__ __launch_bounds__(kMinThreads) void k_replay_table_min(const ReplayArgs r) { replay_table_min_body<SEED>(r); }
 __global__ __launch_bounds__(kThreads) void k_replay_compare(const ReplayArgs r, uint32_t *changed) { replay_compare_body(r, changed); }
-__global__ __launch_bounds__(kThreads) void k_replay_list(const ReplayArgs r, uint32_t *counters) { replay_list_body(r, counters); }
+template <bool CHECK>
+__global__ __launch_bounds__(kThreads) void k_replay_list(const ReplayArgs r, uint32_t *counters) { replay_list_body<CHECK>(r, counters); }
 __global__ __launch_bounds__(kThreads) void k_replay_fold(const ReplayArgs r) { replay_fold_body(r); }
 template <int FMT, bool DC = false>
 __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit(const BatchArgs a, const ReplayArgs r) { replay_emit_body<FMT, DC>(a, r); }
@@ -2445,7 +2600,7 @@ __global__ __launch_bounds__(kThreads) void k_replay_bounds_many(const ChainArgs
     if (!chain_idle(c)) replay_bounds_body(c.r);
 }
 template <bool SEED>
-__global__ __launch_bounds__(kThreads) void k_replay_table_min_many(const ChainArgs *__restrict__ m) {
+__global__ __launch_bounds__(kMinThreads) void k_replay_table_min_many(const ChainArgs *__restrict__ m) {
     const ChainArgs &c = m[blockIdx.y];
     if (!chain_idle(c)) replay_table_min_body<SEED>(c.r);
 }
@@ -2466,9 +2621,10 @@ __global__ __launch_bounds__(1024) void k_replay_blkbase_many(const ChainArgs *_
     if (chain_idle(c)) return;
     replay_blkbase_body(c.r);
 }
+template <bool CHECK>
 __global__ __launch_bounds__(kThreads) void k_replay_list_many(const ChainArgs *__restrict__ m) {
     const ChainArgs &c = m[blockIdx.y];
-    if (!chain_idle(c)) replay_list_body(c.r, c.r.counters);
+    if (!chain_idle(c)) replay_list_body<CHECK>(c.r, c.r.counters);
 }
 template <int FMT>
 __global__ __launch_bounds__(64 * kEmitWaves) void k_replay_emit_many(const ChainArgs *__restrict__ m) {
@@ -3556,15 +3712,44 @@ static bool pessimistic_start() {
 
 hipError_t launch_replay_bounds(const ReplayArgs &r, hipStream_t s) {
     hipLaunchKernelGGL(k_replay_bounds, dim3(item_grid(r.n_items + 1)), dim3(kThreads), 0, s, r);
-    if (r.n_items && r.t_cur && !pessimistic_start()) hipLaunchKernelGGL(k_replay_table_min<true>, dim3(run_grid(r.n_items)), dim3(kThreads), 0, s, r);
+    if (r.n_items && r.t_cur && !pessimistic_start()) hipLaunchKernelGGL(k_replay_table_min<true>, dim3(run_grid(r.n_items)), dim3(kMinThreads), 0, s, r);
     return hipGetLastError();
 }
 
 hipError_t launch_replay_iteration(const BatchArgs &a, const ReplayArgs &r, hipStream_t s) {
     if (r.n_items) hipLaunchKernelGGL(k_replay_score, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);  // (clears counters[kCntChanged])
     hipLaunchKernelGGL(k_replay_walk, dim3((r.nblocks + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, s, r);
-    if (r.n_items) hipLaunchKernelGGL(k_replay_table_min<false>, dim3(run_grid(r.n_items)), dim3(kThreads), 0, s, r);
+    if (r.n_items) hipLaunchKernelGGL(k_replay_table_min<false>, dim3(run_grid(r.n_items)), dim3(kMinThreads), 0, s, r);
     if (r.n_items) hipLaunchKernelGGL(k_replay_compare, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, &a.counters[kCntChanged]);
+    return hipGetLastError();
+}
+
+// RSB_NO_LIST_CHECK=1 (A/B runs): the first round of a chain builds the next table and compares, as every later round does
+static bool list_checks() {
+    static const bool on = [] {
+        const char *e = std::getenv("RSB_NO_LIST_CHECK");
+        return !(e && std::atoi(e) != 0);
+    }();
+    return on;
+}
+
+// The first round of a chain, with the list behind it: "did the table move" is answered by k_replay_list<true> from the walk's result
+// and the current table alone, so the next table is not built unless the answer is yes (launch_replay_next_table).
+hipError_t launch_replay_first_round(const BatchArgs &a, const ReplayArgs &r, hipStream_t s) {
+    if (!list_checks()) {
+        const hipError_t e = launch_replay_iteration(a, r, s);
+        return e != hipSuccess ? e : launch_replay_select(a, r, nullptr, 0, s);
+    }
+    if (r.n_items) hipLaunchKernelGGL(k_replay_score, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);  // (clears counters[kCntChanged])
+    hipLaunchKernelGGL(k_replay_walk, dim3((r.nblocks + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, s, r);
+    hipLaunchKernelGGL(k_replay_blkbase, dim3(1), dim3(1024), 0, s, r);
+    if (r.n_items) hipLaunchKernelGGL(k_replay_list<true>, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, a.counters);
+    return hipGetLastError();
+}
+
+// the table the first round's walk produces (r.acc still holds it), for a batch whose first round was not the fixed point
+hipError_t launch_replay_next_table(const ReplayArgs &r, hipStream_t s) {
+    if (r.n_items) hipLaunchKernelGGL(k_replay_table_min<false>, dim3(run_grid(r.n_items)), dim3(kMinThreads), 0, s, r);
     return hipGetLastError();
 }
 
@@ -3575,7 +3760,7 @@ hipError_t launch_replay_reset(const BatchArgs &, const ReplayArgs &r, uint32_t 
 
 hipError_t launch_replay_select(const BatchArgs &a, const ReplayArgs &r, void *, size_t, hipStream_t s) {
     hipLaunchKernelGGL(k_replay_blkbase, dim3(1), dim3(1024), 0, s, r);
-    if (r.n_items) hipLaunchKernelGGL(k_replay_list, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, a.counters);
+    if (r.n_items) hipLaunchKernelGGL(k_replay_list<false>, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, a.counters);
     return hipGetLastError();
 }
 
@@ -3629,13 +3814,18 @@ hipError_t launch_chain_replay_many(int fmt, const ChainArgs *args_dev, const Ch
     if (d.nch == 0) return hipSuccess;
     const unsigned items = item_grid(d.max_items), items1 = item_grid(d.max_items + 1), runs = run_grid(d.max_items);
     hipLaunchKernelGGL(k_replay_bounds_many, dim3(items1, d.nch), dim3(kThreads), 0, s, args_dev);
-    if (!pessimistic_start()) hipLaunchKernelGGL(k_replay_table_min_many<true>, dim3(runs, d.nch), dim3(kThreads), 0, s, args_dev);
+    if (!pessimistic_start()) hipLaunchKernelGGL(k_replay_table_min_many<true>, dim3(runs, d.nch), dim3(kMinThreads), 0, s, args_dev);
     hipLaunchKernelGGL(k_replay_score_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
     hipLaunchKernelGGL(k_replay_walk_many, dim3((d.max_nblocks + kThreads / 64 - 1) / (kThreads / 64), d.nch), dim3(kThreads), 0, s, args_dev);
-    hipLaunchKernelGGL(k_replay_table_min_many<false>, dim3(runs, d.nch), dim3(kThreads), 0, s, args_dev);
-    hipLaunchKernelGGL(k_replay_compare_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
+    if (!list_checks()) {
+        hipLaunchKernelGGL(k_replay_table_min_many<false>, dim3(runs, d.nch), dim3(kMinThreads), 0, s, args_dev);
+        hipLaunchKernelGGL(k_replay_compare_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
+    }
     hipLaunchKernelGGL(k_replay_blkbase_many, dim3(1, d.nch), dim3(1024), 0, s, args_dev);
-    hipLaunchKernelGGL(k_replay_list_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
+    if (list_checks())
+        hipLaunchKernelGGL(k_replay_list_many<true>, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
+    else
+        hipLaunchKernelGGL(k_replay_list_many<false>, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
     hipError_t e = by_format(fmt, [&](auto F) {
         auto kern = k_replay_emit_many<decltype(F)::value>;
         const hipError_t e2 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmitShared));

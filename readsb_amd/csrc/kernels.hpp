@@ -187,6 +187,8 @@ hipError_t launch_unique_finalize(const BatchArgs &a, uint32_t n_items, int sort
 // the reset of the table that becomes t_next, and the final list / fold / compact / emit step
 hipError_t launch_replay_bounds(const ReplayArgs &r, hipStream_t s);  // once per batch, before the iterations
 hipError_t launch_replay_iteration(const BatchArgs &a, const ReplayArgs &r, hipStream_t s);
+hipError_t launch_replay_first_round(const BatchArgs &a, const ReplayArgs &r, hipStream_t s);  // a chain's first round + the list: no next table
+hipError_t launch_replay_next_table(const ReplayArgs &r, hipStream_t s);                          // ... which this builds when that round moved the table
 hipError_t launch_replay_reset(const BatchArgs &a, const ReplayArgs &r, uint32_t *table, hipStream_t s);
 hipError_t launch_replay_finish(const BatchArgs &a, const ReplayArgs &r, void *temp, size_t temp_bytes, hipStream_t s);
 // the two halves of launch_replay_finish on their own: where every accepted message goes (block bases; total ->

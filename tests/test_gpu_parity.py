@@ -912,6 +912,79 @@ def test_one_scan_launch_for_many_channels(fmt, modeac, built):
         c.close()
 
 
+def seed_miss_recording(n=1 << 17):
+    """A recording on which the device replay's optimistic start is NOT the fixed point (found by tools/find_seed_miss.py on the
+    oracle): B, a clean DF17 of aircraft X, starts 19 bit periods before the end of the stronger DF17 A of another aircraft -- inside A's
+    greedy skip (demod_2400.c:365-371), so the reference never tries it, although it decodes by itself.  The optimistic first-add
+    table says "X known from B on"; the DF4 C that follows would then be accepted.  The reference learns X only from D, rejects C and
+    accepts E."""
+    from readsb_amd.synth import TPS, TPU, _envelope, ap_short, df17, modes_pulse_starts
+
+    X, Y = 0x4CA123, 0x3C6589
+    a, b = df17(Y, bytes.fromhex("3b394f25db74ea")), df17(X, bytes.fromhex("d58a98716313b0"))
+    c, d, e = ap_short(4, X, 0x2345678), df17(X, bytes.fromhex("58b98270a1c3d4")), ap_short(5, X, 0x1234567)
+    ta = 25021
+    tb = ta + (8 + 112 - 19) * TPU + 16
+    bursts = [(ta, a, 0.644), (tb, b, 0.5852), (tb + 400 * TPU, c, 0.5), (tb + 900 * TPU, d, 0.5), (tb + 1400 * TPU, e, 0.5)]
+    rng = np.random.Generator(np.random.PCG64(5))
+    xi = np.zeros(n)
+    for t0, msg, amp in bursts:
+        s0, env = _envelope(modes_pulse_starts(msg), TPU // 2, int(t0))
+        xi[s0:s0 + env.size] += amp * env
+    xi += rng.normal(0, 1.0 / 127.5, n)
+    xq = rng.normal(0, 1.0 / 127.5, n)
+    iq = np.empty((n, 2), dtype=np.uint8)
+    iq[:, 0] = np.clip(np.floor(127.5 + 127.5 * xi + 0.5), 0, 255).astype(np.uint8)
+    iq[:, 1] = np.clip(np.floor(127.5 + 127.5 * xq + 0.5), 0, 255).astype(np.uint8)
+    return iq, (a, b, c, d, e), tb // TPS
+
+
+def seed_miss_is_what_it_claims(iq, frames, b_at, want):
+    a, b, c, d, e = frames
+    msgs = [bytes(r["msg"][:14]) if r["msgbits"] == 112 else bytes(r["msg"][:7]) for r in want]
+    assert a in msgs and d in msgs and e in msgs and b not in msgs and c not in msgs
+    alone, _ = Oracle(fmt="UC8", nfix=1, modeac=False).run_stream(np.ascontiguousarray(iq[b_at - 3:]))
+    assert any(bytes(r["msg"][:14]) == b and r["correctedbits"] == 0 for r in alone)  # B decodes by itself
+
+
+@pytest.mark.parametrize("many", [False, True], ids=["one_channel", "shared_chain"])
+def test_first_round_that_is_not_the_fixed_point(many, built):
+    """The chain's first round answers "did the first-add table move" from the walk's result and the current table alone (no next
+    table is built: k_replay_list<true>).  Here the optimistic table names a message the walk skips: the answer must be yes, the
+    records of that round are dropped, the next table is built then, and the second round is the reference's result."""
+    iq, frames, b_at = seed_miss_recording()
+    want, _ = Oracle(fmt="UC8", nfix=1, modeac=False).run_stream(iq)
+    seed_miss_is_what_it_claims(iq, frames, b_at, want)
+    if not many:
+        ch = readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=1 << 17)
+        got = ch.process_host(iq)
+        assert first_mismatch(want, got.view(REC_DTYPE)) is None
+        assert ch.timing()["replay_on_device"] == 1 and ch.timing()["replay_iterations"] >= 2
+        # and once more on the same channel: X is known now, B is still skipped, C is accepted -- the first round is the fixed point
+        want2, _ = Oracle(fmt="UC8", nfix=1, modeac=False).run_stream(np.concatenate([iq, iq]))
+        got2 = ch.process_host(iq)
+        assert ch.timing()["replay_iterations"] == 1
+        assert [bytes(r["msg"]) for r in got2.view(REC_DTYPE)] == [bytes(r["msg"]) for r in want2[len(want):]]
+        assert len(got2) == len(got) + 1
+        ch.close()
+        return
+    import torch
+
+    nch = 3
+    chans = [readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=1 << 17) for _ in range(nch)]
+    plain = generate(SCENARIOS["mixed_fix1"][0])[: 1 << 17]
+    wantp, _ = Oracle(fmt="UC8", nfix=1, modeac=False).run_stream(plain)
+    devs = [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (plain, iq, plain)]
+    outs = [torch.empty(4096 * 56, dtype=torch.uint8, pin_memory=True).numpy().view(readsb_amd.MSG_DTYPE) for _ in range(nch)]
+    readsb_amd.submit_many(chans, [d.data_ptr() for d in devs], [1 << 17] * nch)
+    parts = readsb_amd.collect_many(chans, outs)
+    for k, w in enumerate((wantp, want, wantp)):
+        assert first_mismatch(w, parts[k].view(REC_DTYPE)) is None, k
+    assert chans[1].timing()["replay_iterations"] >= 2 and chans[0].timing()["replay_iterations"] == 1
+    for ch in chans:
+        ch.close()
+
+
 @pytest.mark.parametrize("pessimistic", [False, True])
 def test_thirty_two_channels_share_one_chain(pessimistic, built, monkeypatch):
     """rsb_collect_many runs the prune / replay / emit chains of all channels as ONE chain of launches (blockIdx.y = channel) with one
