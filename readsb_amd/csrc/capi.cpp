@@ -360,7 +360,9 @@ int replay_enqueue(rsb_ctx *c, rsb_slot &b, uint32_t n_items, bool count_on_devi
     // The first round is followed at once by the list and the records (the optimistic start is nearly always the fixed
     // point): one wait for "did the table move" and the counters together.  If it did move, those records are discarded,
     // the iteration goes on and they are written again.
-    // ("did the table move" is the list kernel's answer and comes back with the counters)
+    // ("did the table move" is the list kernel's answer and comes back with the counters; if it did not, the record kernel folds
+    // the new members into the tables as it goes -- complete when every accepted message got its record, which the host checks)
+    r.fold_with_records = 1;
     HIP_TRY(c, launch_replay_first_round(a, r, s));
     HIP_TRY(c, launch_replay_emit(a, r, s));
     if ((rc = enqueue_readbacks(c, b, r, s)) != RSB_OK) return rc;
@@ -413,6 +415,7 @@ int replay_finish(rsb_ctx *c, rsb_slot &b, hipStream_t s, uint32_t cnt[kCntCount
         if (!changed) {
             converged = true;
             emitted = it == 0;
+            if (emitted && r.fold_with_records) b.chain_folded = cnt[kCntAccepted] <= r.out_cap && (!r.host_out || cnt[kCntAccepted] <= r.host_cap);
         } else {
             // the table this walk produced becomes the current one (a chain's first round has not built it: now); the other goes
             // back to "before this batch"
@@ -428,6 +431,7 @@ int replay_finish(rsb_ctx *c, rsb_slot &b, hipStream_t s, uint32_t cnt[kCntCount
     }
     if (!emitted) {
         int rc;
+        r.fold_with_records = 0;  // (launch_replay_fold below)
         HIP_TRY(c, launch_replay_select(a, r, c->d_sort_temp, c->sort_temp_bytes, s));
         HIP_TRY(c, launch_replay_emit(a, r, s));
         if ((rc = enqueue_readbacks(c, b, r, s)) != RSB_OK) return rc;

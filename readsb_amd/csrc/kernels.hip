@@ -1704,6 +1704,188 @@ __device__ __forceinline__ void prune_write_body(const BatchArgs &a) {
     }
 }
 
+// ---- The ordered prune in ONE pass (round 3, late).  The four kernels above read the items, wrote a keep mask per 64 of them, summed
+// the masks per chunk and per group of chunks, and read masks and kept items again: 41 + 13 + 5 + 47 us per Gsample.  Here a workgroup
+// takes a TILE of 32 consecutive chunks, eight lanes per chunk: it decides and counts its items, learns how many kept items lie
+// before the tile by looking back over the tiles in front of it (each publishes first its own count, then its running total, in one
+// 64-bit word: flag, kept items, all items), and then takes the items once more -- from the cache -- and puts the kept ones in place.
+// A tile's number is its workgroup's: workgroups start in ascending order (per XCD, which take them in turn), so the lowest unfinished
+// tile is always resident and waits for nobody.  (Numbers from a counter, as rocPRIM's look-back scan takes them, cost more than the
+// whole prune: 6000 atomics on one address, one after the other.)  The wait is bounded all the same: a tile that gives up raises
+// kCntOverflow, the batch ends with RSB_EOVERFLOW instead of a hung queue.
+#ifndef RSB_TILE_THREADS
+#define RSB_TILE_THREADS 1024
+#endif
+constexpr int kTileThreads = RSB_TILE_THREADS, kTileChunks = kTileThreads / 8;
+constexpr uint64_t kTileOwn = 1ull << 62, kTileTotal = 2ull << 62;
+#ifndef RSB_TILE_LOADS
+#define RSB_TILE_LOADS 4
+#endif
+constexpr int kTileLoads = RSB_TILE_LOADS;  // items per lane and round (one 64-byte run)
+constexpr int kVerdictRounds = 32 / kTileLoads;
+__device__ __forceinline__ uint64_t tile_pack(uint32_t kept, uint32_t all) { return ((uint64_t)kept << 31) | all; }
+
+// the verdicts on kTileLoads items as a bit mask: first who has to ask the bitmap at all, then those reads together, then the answers
+__device__ __forceinline__ uint32_t tile_keeps(const BatchArgs &a, const uint32_t *summary, bool summarised, const ItemRec (&rec)[kTileLoads]) {
+    uint32_t keep = 0, ask = 0, word[kTileLoads];
+#pragma unroll
+    for (int u = 0; u < kTileLoads; ++u) {
+        const uint32_t combo = item_combo(rec[u].info), v = item_value(rec[u].info), h = summary_bit(v);
+        const bool dead = rec[u].info == kDeadItem;  // padding between the chunks of a region
+        const bool free = a.keep_all != 0 || combo == kComboMarker || !combo_needs_member(combo);
+        keep |= (!dead && free ? 1u : 0u) << u;
+        ask |= (!dead && !free && (!summarised || ((summary[h >> 5] >> (h & 31)) & 1u)) ? 1u : 0u) << u;
+    }
+#pragma unroll
+    for (int u = 0; u < kTileLoads; ++u) word[u] = (ask >> u) & 1u ? a.adder_bitmap[item_value(rec[u].info) >> 5] : 0u;
+#pragma unroll
+    for (int u = 0; u < kTileLoads; ++u) keep |= ((ask >> u) & (word[u] >> (item_value(rec[u].info) & 31)) & 1u) << u;
+    return keep;
+}
+
+__device__ __forceinline__ void prune_onepass_body(const BatchArgs &a) {
+    __shared__ __attribute__((aligned(16))) uint32_t summary[kSummaryWords];
+    __shared__ uint32_t s_before, wave_kept[kTileThreads / 64], wave_all[kTileThreads / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, sub = t & 7;
+    const uint32_t ntiles = (a.n_chunks + kTileChunks - 1) / kTileChunks, tile = blockIdx.x;
+    if (tile >= ntiles) return;  // (a launch for several batches: the grid is the largest batch's)
+    uint64_t *status = a.region_masks;  // (the keep masks' memory: this prune writes none)
+    const bool summarised = a.adder_summary != nullptr;  // uniform over the grid
+    if (summarised && t < kSummaryWords / 4) ((uint4 *)summary)[t] = ((const uint4 *)a.adder_summary)[t];
+    __syncthreads();
+    if (tile == 0) {  // the scan clamps what it writes into a full region and goes on counting: that batch is incomplete
+        bool over = false;
+        for (uint32_t r = t; r < a.n_regions; r += kTileThreads) over |= a.region_counts[r] > a.item_region;
+        if (over) atomicAdd(&a.counters[kCntOverflow], 1u);
+    }
+    const uint32_t c = tile * kTileChunks + (t >> 3);
+    const uint2 d = c < a.n_chunks ? a.chunk_dir[c] : make_uint2(0, 0);
+    const ItemRec *items = a.items + d.x;
+    // the lane's items of round k: k * 8 * kTileLoads + sub + 8 u (a load instruction takes a run of eight items per chunk); the verdicts of
+    // the first rounds stay in a register
+    uint32_t kept = 0, verdicts = 0, round = 0;
+    for (uint32_t k0 = sub; k0 < d.y; k0 += 8 * kTileLoads, ++round) {
+        ItemRec rec[kTileLoads];
+#pragma unroll
+        for (int u = 0; u < kTileLoads; ++u) rec[u] = k0 + 8 * u < d.y ? items[k0 + 8 * u] : ItemRec{0, kDeadItem};
+        const uint32_t keep = tile_keeps(a, summary, summarised, rec);
+        kept += (uint32_t)__popc(keep);
+        if (round < (uint32_t)kVerdictRounds) verdicts |= keep << (round * kTileLoads);
+    }
+    // the chunk's count (in all eight lanes), the chunks before it in the wavefront, the wavefronts before it in the tile
+    uint32_t chunk_keeps = kept;
+    for (int off = 1; off < 8; off <<= 1) chunk_keeps += (uint32_t)__shfl_xor((int)chunk_keeps, off, 64);
+    uint32_t incl = chunk_keeps, incl_all = d.y;
+    for (int off = 8; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64), up_all = (uint32_t)__shfl_up((int)incl_all, off, 64);
+        if ((int)lane >= off) {
+            incl += up;
+            incl_all += up_all;
+        }
+    }
+    if (lane == 63) {
+        wave_kept[wave] = incl;
+        wave_all[wave] = incl_all;
+    }
+    __syncthreads();
+    if (wave == 0) {  // the look-back, 64 tiles at a time
+        uint32_t own_kept = 0, own_all = 0;
+        for (uint32_t w = 0; w < kTileThreads / 64; ++w) {
+            own_kept += wave_kept[w];
+            own_all += wave_all[w];
+        }
+        if (tile && lane == 0) __hip_atomic_store(&status[tile], kTileOwn | tile_pack(own_kept, own_all), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t run_kept = 0, run_all = 0, spins = 0;
+        bool gave_up = false;
+        for (int64_t p = (int64_t)tile - 1; p >= 0;) {
+            const int64_t q = p - (int64_t)lane;
+            const uint64_t st = q >= 0 ? __hip_atomic_load(&status[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kTileTotal;  // (in front of tile 0: nothing)
+            const uint64_t totals = __ballot((st >> 62) == 2), blanks = __ballot((st >> 62) == 0);
+            const uint32_t upto = (uint32_t)__builtin_ctzll(totals | (1ull << 63));  // the nearest running total, or all 64
+            const uint64_t span = upto == 63 ? ~0ull : (2ull << upto) - 1ull;
+            if (blanks & span) {  // someone in between has not published yet
+                if (++spins > (1u << 16)) {  // (a load is about a microsecond: tens of milliseconds, a thousand times what a tile takes)
+                    gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            uint32_t k = (span >> lane) & 1ull ? (uint32_t)(st >> 31) & 0x7fffffffu : 0u, al = (span >> lane) & 1ull ? (uint32_t)st & 0x7fffffffu : 0u;
+            for (int off = 32; off > 0; off >>= 1) {
+                k += (uint32_t)__shfl_xor((int)k, off, 64);
+                al += (uint32_t)__shfl_xor((int)al, off, 64);
+            }
+            run_kept += k;
+            run_all += al;
+            if (totals & span) break;
+            p -= 64;
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&status[tile], kTileTotal | tile_pack(run_kept + own_kept, run_all + own_all), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gave_up) atomicAdd(&a.counters[kCntOverflow], 1u);
+            if (tile == ntiles - 1) {
+                a.counters[kCntSurvItems] = run_kept + own_kept;
+                a.counters[kCntItemsTotal] = run_all + own_all;
+            }
+            s_before = run_kept;
+        }
+    }
+    __syncthreads();
+    uint32_t slot = s_before + incl - chunk_keeps;  // the chunk's first place
+    for (uint32_t w = 0; w < wave; ++w) slot += wave_kept[w];
+    // once more, in order: round after round, within a round load after load, within a load lane after lane.  (The rounds of a wavefront
+    // run to its longest chunk: the shuffles need every lane.  Only rounds with a kept item read their items again.)
+    uint32_t most = d.y;
+    for (int off = 8; off < 64; off <<= 1) most = max(most, (uint32_t)__shfl_xor((int)most, off, 64));
+    round = 0;
+    for (uint32_t r0 = 0; r0 < most; r0 += 8 * kTileLoads, ++round) {
+        const uint32_t k0 = r0 + sub;
+        ItemRec rec[kTileLoads];
+        uint32_t keep;
+        if (round < (uint32_t)kVerdictRounds) {
+            keep = (verdicts >> (round * kTileLoads)) & ((1u << kTileLoads) - 1u);
+#pragma unroll
+            for (int u = 0; u < kTileLoads; ++u)
+                if ((keep >> u) & 1u) rec[u] = items[k0 + 8 * u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < kTileLoads; ++u) rec[u] = k0 + 8 * u < d.y ? items[k0 + 8 * u] : ItemRec{0, kDeadItem};
+            keep = tile_keeps(a, summary, summarised, rec);
+        }
+        // load u of the eight lanes is one run of eight items: the kept ones of run 0 come first, then run 1's ...; the four counts
+        // travel through the eight-lane sum as the bytes of one word
+        static_assert(kTileLoads <= 8, "one byte per load in a 64-bit word");
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int u = 0; u < kTileLoads; ++u) mine |= (unsigned long long)((keep >> u) & 1u) << (8 * u);
+        unsigned long long upto = mine;
+        for (int off = 1; off < 8; off <<= 1) {
+            const unsigned long long up = __shfl_up(upto, off, 8);
+            if ((int)sub >= off) upto += up;
+        }
+        const unsigned long long all = __shfl(upto, 7, 8), before = upto - mine;
+#pragma unroll
+        for (int u = 0; u < kTileLoads; ++u) {
+            const uint32_t at = slot + ((uint32_t)(before >> (8 * u)) & 0xffu);
+            if (((keep >> u) & 1u) && at < a.surv_item_cap) {
+                a.skeys[0][at] = ((uint64_t)rec[u].g << 3) | item_phase(rec[u].info);
+                a.sinfo[0][at] = rec[u].info;
+            }
+            slot += (uint32_t)(all >> (8 * u)) & 0xffu;
+        }
+    }
+}
+__global__ __launch_bounds__(kTileThreads) void k_prune_onepass(const BatchArgs a) { prune_onepass_body(a); }
+// in front of it: the tiles' words and the ticket back to zero (and, for batches that use it, the summary's words: the memset's place)
+__device__ __forceinline__ void prune_tiles_clear_body(const BatchArgs &a) {
+    const uint32_t ntiles = (a.n_chunks + kTileChunks - 1) / kTileChunks;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < ntiles; i += gridDim.x * kThreads) a.region_masks[i] = 0;
+    static_assert(kSummaryWords == 4 * kThreads, "one 16-byte piece per thread");
+    if (blockIdx.x == 0 && a.adder_summary) ((uint4 *)a.adder_summary)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+}
+__global__ __launch_bounds__(kThreads) void k_prune_tiles_clear(const BatchArgs a) { prune_tiles_clear_body(a); }
+
 __global__ __launch_bounds__(kThreads) void k_keys_to_g(const uint64_t *keys, uint32_t *g, uint32_t n) {
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) g[i] = (uint32_t)(keys[i] >> 3);
 }
@@ -1897,11 +2079,12 @@ __device__ __forceinline__ void replay_score_body(const ReplayArgs &r) {
 }
 
 // One wavefront per 131072-sample block (one demodulate2400 call): the offsets that could be accepted, 64 items at a
-// time, are chained in ascending order through the greedy skip (demod_2400.c:371) -- the only sequential part.
+// time, are chained in ascending order through the greedy skip (demod_2400.c:371) -- the only sequential part.  The candidates go
+// through an LDS queue (offset, where the scan goes on if taken); the chain reads them eight at a time ahead of the comparisons and
+// keeps its verdicts in a 64-bit mask -- a store per step (round 2's form) made every step wait for its own LDS reads.  (The chain on
+// the scalar unit, v_readlane of the candidates' lanes in ballot order: 33 us against 27.)
 __device__ __forceinline__ void replay_walk_body(const ReplayArgs &r) {
-    __shared__ uint32_t cand_g[kThreads / 64][64];
-    __shared__ uint32_t cand_len[kThreads / 64][64];
-    __shared__ uint32_t cand_ok[kThreads / 64][64];   // 0, or 1 + the message's rank among the block's accepted messages
+    __shared__ uint2 cand_q[kThreads / 64][64];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * (kThreads / 64) + wave;
     if (b >= r.nblocks) return;  // whole wavefronts leave; no workgroup barrier below
@@ -1924,23 +2107,25 @@ __device__ __forceinline__ void replay_walk_body(const ReplayArgs &r) {
         const uint64_t cm = __ballot(cand);
         const uint32_t pos = lanes_below(cm), nc = (uint32_t)__popcll(cm);
         wave_sync();
-        if (cand) {
-            cand_g[wave][pos] = g;
-            cand_len[wave][pos] = (c >> 20) ? 268u : 134u;
-        }
+        if (cand) cand_q[wave][pos] = make_uint2(g, g + ((c >> 20) ? 268u : 134u) + 1);
         wave_sync();
-        for (uint32_t k = 0; k < nc; ++k) {  // every lane runs the same chain
-            const uint32_t cg = cand_g[wave][k];
-            const bool take = cg >= next_j;
-            if (take) next_j = cg + cand_len[wave][k] + 1;
-            if (lane == 0) cand_ok[wave][k] = take ? accepted + 1 : 0u;
-            accepted += take;
+        uint64_t taken = 0;  // by queue position
+        for (uint32_t k0 = 0; k0 < nc; k0 += 8) {  // every lane runs the same chain
+            uint2 q[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) q[u] = cand_q[wave][(k0 + u) & 63u];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const bool take = k0 + u < nc && q[u].x >= next_j;
+                next_j = take ? q[u].y : next_j;
+                taken |= (uint64_t)take << (k0 + u);
+            }
         }
-        wave_sync();
-        if (cand && cand_ok[wave][pos]) {
+        if (cand && ((taken >> pos) & 1ull)) {
             r.acc[i + ((c >> 16) & 15u)] = c & 0xffffu;
-            r.acc_rank[i + ((c >> 16) & 15u)] = cand_ok[wave][pos] - 1;  // k_replay_emit: the record's place = the block's base + this
+            r.acc_rank[i + ((c >> 16) & 15u)] = accepted + (uint32_t)__popcll(taken & ((1ull << pos) - 1ull));  // k_replay_emit: the record's place = the block's base + this
         }
+        accepted += (uint32_t)__popcll(taken);
     }
     if (lane == 0) r.blk_counts[b] = accepted;
 }
@@ -2243,6 +2428,7 @@ __device__ __forceinline__ void replay_emit_body(const BatchArgs &a, const Repla
 #define EMIT_STAMP(k)
 #endif
     uint32_t nacc = r.counters[kCntAccepted];
+    const bool folds = r.fold_with_records != 0 && r.counters[kCntChanged] == 0;  // (the list kernel's verdict on this round)
     if (nacc > r.out_cap) nacc = r.out_cap;
     if (r.host_out && nacc > r.host_cap) nacc = r.host_cap;
     uint32_t by_errors[3] = {0, 0, 0};  // wave-uniform
@@ -2261,6 +2447,13 @@ __device__ __forceinline__ void replay_emit_body(const BatchArgs &a, const Repla
             phase = (uint32_t)key & 7u;
             info = r.info[idx];
             score = r.acc[idx] - 1;
+            // the batch's new members become "known before the next batch" (k_replay_fold, here for the price of two stores: at a
+            // fixed point every address the batch taught the filter has an accepted message that adds it)
+            if (folds && combo_adds(item_combo(info))) {
+                const uint32_t v = item_value(info);
+                r.t_cur[v] = 0;
+                r.t_next[v] = 0;
+            }
         }
         const uint32_t combo = item_combo(info);
         const bool lng = !combo_is_short(combo);
@@ -2578,6 +2771,14 @@ __global__ __launch_bounds__(kThreads) void k_prune_summary_many(const ChainArgs
     const ChainArgs &c = m[blockIdx.y];
     if (chain_idle(c) || !c.a.adder_summary) return;
     prune_summary_body(c.a.adder_bitmap, c.a.adder_summary);
+}
+__global__ __launch_bounds__(kThreads) void k_prune_tiles_clear_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) prune_tiles_clear_body(c.a);
+}
+__global__ __launch_bounds__(kTileThreads) void k_prune_onepass_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) prune_onepass_body(c.a);
 }
 __global__ __launch_bounds__(kThreads) void k_prune_count_many(const ChainArgs *__restrict__ m) {
     const ChainArgs &c = m[blockIdx.y];
@@ -3636,8 +3837,22 @@ hipError_t launch_prune(const BatchArgs &a, hipStream_t s) {
 
 // the kept items packed in stream order (already sorted: no launch_sort behind it).  Valid when nothing took the scan kernel's
 // per-thread paths (counters[kCntItems] == 0: the shared region is empty) and no marker items were asked for.
+// RSB_PRUNE_FOUR_PASSES=1 (A/B runs): keep masks, counts per chunk, offsets, write -- as until late in round 3
+static bool prune_one_pass() {
+    const char *e = std::getenv("RSB_PRUNE_FOUR_PASSES");
+    return !(e && std::atoi(e) != 0);
+}
+static unsigned tiles_of(uint32_t n_chunks) { return n_chunks ? (n_chunks + kTileChunks - 1) / kTileChunks : 1u; }
+
 hipError_t launch_prune_ordered(const BatchArgs &a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
+    if (prune_one_pass()) {
+        const unsigned tiles = tiles_of(a.n_chunks), clear = (tiles + kThreads - 1) / kThreads;
+        hipLaunchKernelGGL(k_prune_tiles_clear, dim3(clear > 64 ? 64 : clear), dim3(kThreads), 0, s, a);
+        if (a.adder_summary) hipLaunchKernelGGL(k_prune_summary, dim3((1u << 24) / 32 / 4 / kThreads), dim3(kThreads), 0, s, a.adder_bitmap, a.adder_summary);
+        hipLaunchKernelGGL(k_prune_onepass, dim3(tiles), dim3(kTileThreads), 0, s, a);
+        return hipGetLastError();
+    }
     if (a.adder_summary) {
         const hipError_t e = hipMemsetAsync(a.adder_summary, 0, kSummaryWords * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
@@ -3726,11 +3941,8 @@ hipError_t launch_replay_iteration(const BatchArgs &a, const ReplayArgs &r, hipS
 
 // RSB_NO_LIST_CHECK=1 (A/B runs): the first round of a chain builds the next table and compares, as every later round does
 static bool list_checks() {
-    static const bool on = [] {
-        const char *e = std::getenv("RSB_NO_LIST_CHECK");
-        return !(e && std::atoi(e) != 0);
-    }();
-    return on;
+    const char *e = std::getenv("RSB_NO_LIST_CHECK");
+    return !(e && std::atoi(e) != 0);
 }
 
 // The first round of a chain, with the list behind it: "did the table move" is answered by k_replay_list<true> from the walk's result
@@ -3797,6 +4009,13 @@ hipError_t launch_replay_emit(const BatchArgs &a, const ReplayArgs &r, hipStream
 // One launch per stage for all the channels' batches (args_dev[i] = channel i's {BatchArgs, ReplayArgs}; d gives the grids' extents).
 hipError_t launch_chain_prune_many(const ChainArgs *args_dev, const ChainDims &d, hipStream_t s) {
     if (d.nch == 0) return hipSuccess;
+    if (prune_one_pass()) {
+        const unsigned tiles = tiles_of(d.max_chunks), clear = (tiles + kThreads - 1) / kThreads;
+        hipLaunchKernelGGL(k_prune_tiles_clear_many, dim3(clear > 64 ? 64 : clear, d.nch), dim3(kThreads), 0, s, args_dev);
+        if (d.any_summary) hipLaunchKernelGGL(k_prune_summary_many, dim3((1u << 24) / 32 / 4 / kThreads, d.nch), dim3(kThreads), 0, s, args_dev);
+        hipLaunchKernelGGL(k_prune_onepass_many, dim3(tiles, d.nch), dim3(kTileThreads), 0, s, args_dev);
+        return hipGetLastError();
+    }
     if (d.any_summary) {
         hipLaunchKernelGGL(k_prune_summary_clear_many, dim3(1, d.nch), dim3(kThreads), 0, s, args_dev);
         hipLaunchKernelGGL(k_prune_summary_many, dim3((1u << 24) / 32 / 4 / kThreads, d.nch), dim3(kThreads), 0, s, args_dev);

@@ -136,6 +136,7 @@ struct ReplayArgs {
     uint32_t n_cap;
     uint32_t *counters;      // the batch's device counters (kernels.hpp enum)
     uint32_t *acc;           // per item: score + 1 if this (offset, phase) is decoded and accepted, else 0
+    uint32_t fold_with_records;  // k_replay_emit also does k_replay_fold's work for the messages it writes (a chain whose first round holds)
     uint32_t *cand;          // per item: k_replay_score's verdict for the offset that starts there (scratch)
     uint32_t *acc_rank;      // per accepted item: its rank among the accepted messages of its 131072-sample block (k_replay_walk)
     uint32_t *blk_base;      // accepted messages before every block, nblocks + 1 entries (k_replay_blkbase)

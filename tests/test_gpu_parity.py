@@ -985,6 +985,27 @@ def test_first_round_that_is_not_the_fixed_point(many, built):
         ch.close()
 
 
+@pytest.mark.parametrize("switch", ["RSB_PRUNE_FOUR_PASSES", "RSB_NO_LIST_CHECK"])
+def test_chain_variants_kept_for_comparison(switch, built, monkeypatch):
+    """The forms the chain had until late in round 3 stay behind switches for A/B runs (tools/ab_env.sh): the ordered prune in four
+    passes with keep masks (now one pass with a look-back over tiles), and a first round that builds the next first-add table and
+    compares (now answered by the list kernel).  Same lists, against the oracle, also on the recording whose first round moves the table."""
+    monkeypatch.setenv(switch, "1")
+    sc, kw = SCENARIOS["mixed_fix1"]
+    iq = generate(sc)
+    want, _ = Oracle(fmt=sc.fmt, nfix=kw["nfix"], modeac=False).run_stream(iq)
+    ch = readsb_amd.Channel(fmt=sc.fmt, fix_bits=kw["nfix"], max_batch_samples=1 << 21)
+    assert first_mismatch(want, ch.process_host(iq).view(REC_DTYPE)) is None
+    assert ch.timing()["replay_on_device"] == 1
+    ch.close()
+    iq, frames, b_at = seed_miss_recording()
+    want, _ = Oracle(fmt="UC8", nfix=1, modeac=False).run_stream(iq)
+    ch = readsb_amd.Channel(fmt="UC8", fix_bits=1, max_batch_samples=1 << 17)
+    assert first_mismatch(want, ch.process_host(iq).view(REC_DTYPE)) is None
+    assert ch.timing()["replay_iterations"] >= 2
+    ch.close()
+
+
 @pytest.mark.parametrize("pessimistic", [False, True])
 def test_thirty_two_channels_share_one_chain(pessimistic, built, monkeypatch):
     """rsb_collect_many runs the prune / replay / emit chains of all channels as ONE chain of launches (blockIdx.y = channel) with one
