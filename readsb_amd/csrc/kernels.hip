@@ -1959,14 +1959,14 @@ __device__ __forceinline__ uint32_t items_of(const ReplayArgs &r) { return r.n_d
 
 // first item of every 131072-sample block in the sorted item list (blk_start[nblocks] = n_items); also clears the counters the
 // replay's later kernels add to
-__device__ __forceinline__ void replay_bounds_body(const ReplayArgs &r) {
+__device__ __forceinline__ void replay_bounds_body(const ReplayArgs &r, uint32_t block, uint32_t nblocks, uint32_t nthreads) {
     const uint32_t n_items = items_of(r);
-    if (blockIdx.x == 0 && threadIdx.x < 6 && r.counters) {
+    if (block == 0 && threadIdx.x < 6 && r.counters) {
         static_assert(kCntNewAdders == kCntAccepted + 1 && kCntAccE0 == kCntAccepted + 2 && kCntAccE2 == kCntAccepted + 4, "one run of counters");
         if (threadIdx.x < 5) r.counters[kCntAccepted + threadIdx.x] = 0;
         else r.counters[kCntChanged] = 0;
     }
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i <= n_items; i += gridDim.x * kThreads) {
+    for (uint32_t i = block * nthreads + threadIdx.x; i <= n_items; i += nblocks * nthreads) {
         const int64_t prev = i == 0 ? -1 : (int64_t)min((uint64_t)r.nblocks, (r.keys[i - 1] >> 3) / r.block_len);
         const int64_t cur = i == n_items ? (int64_t)r.nblocks : (int64_t)min((uint64_t)r.nblocks, (r.keys[i] >> 3) / r.block_len);
         for (int64_t b = prev + 1; b <= cur; ++b) r.blk_start[b] = i;
@@ -2186,7 +2186,7 @@ __device__ __forceinline__ void replay_blkbase_body(const ReplayArgs &r) {
 #endif
 constexpr int kMinSlots = RSB_MIN_SLOTS, kMinThreads = RSB_MIN_THREADS, kMinItemsPerGroup = RSB_MIN_ITEMS;
 template <bool SEED>
-__device__ __forceinline__ void replay_table_min_body(const ReplayArgs &r) {
+__device__ __forceinline__ void replay_table_min_body(const ReplayArgs &r, uint32_t nruns) {  // nruns: the workgroups that take runs (they stride by it)
     __shared__ uint32_t key[kMinSlots], val[kMinSlots];
     uint32_t *table = SEED ? r.t_cur : r.t_next;
     // (the grid is sized from the host's bound on the kept items, ten times the count on ordinary traffic: most workgroups have no run)
@@ -2197,7 +2197,7 @@ __device__ __forceinline__ void replay_table_min_body(const ReplayArgs &r) {
     }
     __syncthreads();
     const uint32_t n_items = items_of(r);
-    for (uint32_t lo = blockIdx.x * (uint32_t)kMinItemsPerGroup; lo < n_items; lo += gridDim.x * (uint32_t)kMinItemsPerGroup) {  // (one run per workgroup when the host's bound holds)
+    for (uint32_t lo = blockIdx.x * (uint32_t)kMinItemsPerGroup; lo < n_items; lo += nruns * (uint32_t)kMinItemsPerGroup) {  // (one run per workgroup when the host's bound holds)
         const uint32_t hi = min(n_items, lo + (uint32_t)kMinItemsPerGroup);
 #if RSB_MIN_BATCH_ITEMS
         // (a thread's items are all loaded before the first of them goes to the LDS table: one round trip to memory instead of one per item)
@@ -2747,12 +2747,19 @@ __global__ __launch_bounds__(kThreads) void k_prune_count(const BatchArgs a) { p
 __global__ __launch_bounds__(kChunkGroup) void k_prune_chunks(const BatchArgs a) { prune_chunks_body(a); }
 __global__ __launch_bounds__(1024) void k_prune_offsets(const BatchArgs a) { prune_offsets_body(a); }
 __global__ __launch_bounds__(kThreads) void k_prune_write(const BatchArgs a) { prune_write_body(a); }
-__global__ __launch_bounds__(kThreads) void k_replay_bounds(const ReplayArgs r) { replay_bounds_body(r); }
+__global__ __launch_bounds__(kThreads) void k_replay_bounds(const ReplayArgs r) { replay_bounds_body(r, blockIdx.x, gridDim.x, kThreads); }
 __global__ __launch_bounds__(kThreads) void k_replay_score(const ReplayArgs r) { replay_score_body(r); }
 __global__ __launch_bounds__(kThreads) void k_replay_walk(const ReplayArgs r) { replay_walk_body(r); }
 __global__ __launch_bounds__(1024) void k_replay_blkbase(const ReplayArgs r) { replay_blkbase_body(r); }
 template <bool SEED>
-__global__ __launch_bounds__(kMinThreads) void k_replay_table_min(const ReplayArgs r) { replay_table_min_body<SEED>(r); }
+__global__ __launch_bounds__(kMinThreads) void k_replay_table_min(const ReplayArgs r) { replay_table_min_body<SEED>(r, gridDim.x); }
+// the optimistic table and the blocks' first items in one launch (neither needs the other: workgroups [0, runs) / [runs, gridDim.x))
+__global__ __launch_bounds__(kMinThreads) void k_replay_seed_bounds(const ReplayArgs r, uint32_t runs) {
+    if (blockIdx.x < runs)
+        replay_table_min_body<true>(r, runs);
+    else
+        replay_bounds_body(r, blockIdx.x - runs, gridDim.x - runs, kMinThreads);
+}
 __global__ __launch_bounds__(kThreads) void k_replay_compare(const ReplayArgs r, uint32_t *changed) { replay_compare_body(r, changed); }
 template <bool CHECK>
 __global__ __launch_bounds__(kThreads) void k_replay_list(const ReplayArgs r, uint32_t *counters) { replay_list_body<CHECK>(r, counters); }
@@ -2798,12 +2805,20 @@ __global__ __launch_bounds__(kThreads) void k_prune_write_many(const ChainArgs *
 }
 __global__ __launch_bounds__(kThreads) void k_replay_bounds_many(const ChainArgs *__restrict__ m) {
     const ChainArgs &c = m[blockIdx.y];
-    if (!chain_idle(c)) replay_bounds_body(c.r);
+    if (!chain_idle(c)) replay_bounds_body(c.r, blockIdx.x, gridDim.x, kThreads);
+}
+__global__ __launch_bounds__(kMinThreads) void k_replay_seed_bounds_many(const ChainArgs *__restrict__ m, uint32_t runs) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (chain_idle(c)) return;
+    if (blockIdx.x < runs)
+        replay_table_min_body<true>(c.r, runs);
+    else
+        replay_bounds_body(c.r, blockIdx.x - runs, gridDim.x - runs, kMinThreads);
 }
 template <bool SEED>
 __global__ __launch_bounds__(kMinThreads) void k_replay_table_min_many(const ChainArgs *__restrict__ m) {
     const ChainArgs &c = m[blockIdx.y];
-    if (!chain_idle(c)) replay_table_min_body<SEED>(c.r);
+    if (!chain_idle(c)) replay_table_min_body<SEED>(c.r, gridDim.x);
 }
 __global__ __launch_bounds__(kThreads) void k_replay_score_many(const ChainArgs *__restrict__ m) {
     const ChainArgs &c = m[blockIdx.y];
@@ -3925,9 +3940,20 @@ static bool pessimistic_start() {
     return e && std::atoi(e) != 0;
 }
 
+namespace {
+inline unsigned bounds_blocks(uint32_t n) {  // k_replay_seed_bounds: 1024-thread workgroups for the blocks' first items
+    const unsigned g = (n + kMinThreads) / kMinThreads;
+    return g > 512 ? 512 : g;
+}
+}  // namespace
+
 hipError_t launch_replay_bounds(const ReplayArgs &r, hipStream_t s) {
-    hipLaunchKernelGGL(k_replay_bounds, dim3(item_grid(r.n_items + 1)), dim3(kThreads), 0, s, r);
-    if (r.n_items && r.t_cur && !pessimistic_start()) hipLaunchKernelGGL(k_replay_table_min<true>, dim3(run_grid(r.n_items)), dim3(kMinThreads), 0, s, r);
+    if (r.n_items && r.t_cur && !pessimistic_start()) {
+        const unsigned runs = run_grid(r.n_items);
+        hipLaunchKernelGGL(k_replay_seed_bounds, dim3(runs + bounds_blocks(r.n_items)), dim3(kMinThreads), 0, s, r, runs);
+    } else {
+        hipLaunchKernelGGL(k_replay_bounds, dim3(item_grid(r.n_items + 1)), dim3(kThreads), 0, s, r);
+    }
     return hipGetLastError();
 }
 
@@ -4032,8 +4058,10 @@ hipError_t launch_chain_replay_many(int fmt, const ChainArgs *args_dev, const Ch
                                     hipStream_t s) {
     if (d.nch == 0) return hipSuccess;
     const unsigned items = item_grid(d.max_items), items1 = item_grid(d.max_items + 1), runs = run_grid(d.max_items);
-    hipLaunchKernelGGL(k_replay_bounds_many, dim3(items1, d.nch), dim3(kThreads), 0, s, args_dev);
-    if (!pessimistic_start()) hipLaunchKernelGGL(k_replay_table_min_many<true>, dim3(runs, d.nch), dim3(kMinThreads), 0, s, args_dev);
+    if (!pessimistic_start())
+        hipLaunchKernelGGL(k_replay_seed_bounds_many, dim3(runs + bounds_blocks(d.max_items), d.nch), dim3(kMinThreads), 0, s, args_dev, runs);
+    else
+        hipLaunchKernelGGL(k_replay_bounds_many, dim3(items1, d.nch), dim3(kThreads), 0, s, args_dev);
     hipLaunchKernelGGL(k_replay_score_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
     hipLaunchKernelGGL(k_replay_walk_many, dim3((d.max_nblocks + kThreads / 64 - 1) / (kThreads / 64), d.nch), dim3(kThreads), 0, s, args_dev);
     if (!list_checks()) {
