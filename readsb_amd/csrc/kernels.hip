@@ -1722,14 +1722,16 @@ constexpr uint64_t kTileOwn = 1ull << 62, kTileTotal = 2ull << 62;
 #define RSB_TILE_LOADS 4
 #endif
 constexpr int kTileLoads = RSB_TILE_LOADS;  // items per lane and round (one 64-byte run)
-constexpr int kVerdictRounds = 32 / kTileLoads;
+constexpr int kVerdictRounds = 32 / kTileLoads, kHeadRounds = 3;
+static_assert(kHeadRounds <= kVerdictRounds, "the head's verdicts fit the register");
 __device__ __forceinline__ uint64_t tile_pack(uint32_t kept, uint32_t all) { return ((uint64_t)kept << 31) | all; }
 
 // the verdicts on kTileLoads items as a bit mask: first who has to ask the bitmap at all, then those reads together, then the answers
-__device__ __forceinline__ uint32_t tile_keeps(const BatchArgs &a, const uint32_t *summary, bool summarised, const ItemRec (&rec)[kTileLoads]) {
-    uint32_t keep = 0, ask = 0, word[kTileLoads];
+template <int N>
+__device__ __forceinline__ uint32_t tile_keeps(const BatchArgs &a, const uint32_t *summary, bool summarised, const ItemRec (&rec)[N]) {
+    uint32_t keep = 0, ask = 0, word[N];
 #pragma unroll
-    for (int u = 0; u < kTileLoads; ++u) {
+    for (int u = 0; u < N; ++u) {
         const uint32_t combo = item_combo(rec[u].info), v = item_value(rec[u].info), h = summary_bit(v);
         const bool dead = rec[u].info == kDeadItem;  // padding between the chunks of a region
         const bool free = a.keep_all != 0 || combo == kComboMarker || !combo_needs_member(combo);
@@ -1737,9 +1739,9 @@ __device__ __forceinline__ uint32_t tile_keeps(const BatchArgs &a, const uint32_
         ask |= (!dead && !free && (!summarised || ((summary[h >> 5] >> (h & 31)) & 1u)) ? 1u : 0u) << u;
     }
 #pragma unroll
-    for (int u = 0; u < kTileLoads; ++u) word[u] = (ask >> u) & 1u ? a.adder_bitmap[item_value(rec[u].info) >> 5] : 0u;
+    for (int u = 0; u < N; ++u) word[u] = (ask >> u) & 1u ? a.adder_bitmap[item_value(rec[u].info) >> 5] : 0u;
 #pragma unroll
-    for (int u = 0; u < kTileLoads; ++u) keep |= ((ask >> u) & (word[u] >> (item_value(rec[u].info) & 31)) & 1u) << u;
+    for (int u = 0; u < N; ++u) keep |= ((ask >> u) & (word[u] >> (item_value(rec[u].info) & 31)) & 1u) << u;
     return keep;
 }
 
@@ -1763,8 +1765,17 @@ __device__ __forceinline__ void prune_onepass_body(const BatchArgs &a) {
     const ItemRec *items = a.items + d.x;
     // the lane's items of round k: k * 8 * kTileLoads + sub + 8 u (a load instruction takes a run of eight items per chunk); the verdicts of
     // the first rounds stay in a register
-    uint32_t kept = 0, verdicts = 0, round = 0;
-    for (uint32_t k0 = sub; k0 < d.y; k0 += 8 * kTileLoads, ++round) {
+    // The first kHeadRounds rounds (96 items: most chunks end there) go as one: their loads together, then the verdicts, then the
+    // bitmap reads of all of them -- two trips to memory where round after round made six.
+    uint32_t kept = 0, verdicts = 0, round = kHeadRounds;
+    {
+        ItemRec rec[kHeadRounds * kTileLoads];
+#pragma unroll
+        for (int u = 0; u < kHeadRounds * kTileLoads; ++u) rec[u] = sub + 8 * u < d.y ? items[sub + 8 * u] : ItemRec{0, kDeadItem};
+        verdicts = tile_keeps(a, summary, summarised, rec);
+        kept = (uint32_t)__popc(verdicts);
+    }
+    for (uint32_t k0 = sub + 8 * kHeadRounds * kTileLoads; k0 < d.y; k0 += 8 * kTileLoads, ++round) {
         ItemRec rec[kTileLoads];
 #pragma unroll
         for (int u = 0; u < kTileLoads; ++u) rec[u] = k0 + 8 * u < d.y ? items[k0 + 8 * u] : ItemRec{0, kDeadItem};
@@ -1838,12 +1849,24 @@ __device__ __forceinline__ void prune_onepass_body(const BatchArgs &a) {
     // run to its longest chunk: the shuffles need every lane.  Only rounds with a kept item read their items again.)
     uint32_t most = d.y;
     for (int off = 8; off < 64; off <<= 1) most = max(most, (uint32_t)__shfl_xor((int)most, off, 64));
+    ItemRec head[kHeadRounds * kTileLoads];
+#pragma unroll
+    for (int u = 0; u < kHeadRounds * kTileLoads; ++u)
+        if ((verdicts >> u) & 1u) head[u] = items[sub + 8 * u];
     round = 0;
     for (uint32_t r0 = 0; r0 < most; r0 += 8 * kTileLoads, ++round) {
         const uint32_t k0 = r0 + sub;
         ItemRec rec[kTileLoads];
         uint32_t keep;
-        if (round < (uint32_t)kVerdictRounds) {
+        if (round < (uint32_t)kHeadRounds) {
+            keep = (verdicts >> (round * kTileLoads)) & ((1u << kTileLoads) - 1u);
+#pragma unroll
+            for (int h = 0; h < kHeadRounds; ++h)  // (static indices into head[]: a register array)
+                if (round == (uint32_t)h) {
+#pragma unroll
+                    for (int u = 0; u < kTileLoads; ++u) rec[u] = head[h * kTileLoads + u];
+                }
+        } else if (round < (uint32_t)kVerdictRounds) {
             keep = (verdicts >> (round * kTileLoads)) & ((1u << kTileLoads) - 1u);
 #pragma unroll
             for (int u = 0; u < kTileLoads; ++u)
@@ -1983,6 +2006,13 @@ __device__ __forceinline__ void replay_bounds_body(const ReplayArgs &r, uint32_t
 #ifndef RSB_SCORE_SERIAL
 #define RSB_SCORE_SERIAL 0
 #endif
+// an item's score given the first-add table's entry for its address: (score + 4) | decodeModesMessage takes it << 12 | 112-bit frame << 13
+// (score -3 .. 1800: never 0, which stands for a marker item)
+__device__ __forceinline__ uint32_t score_word(uint32_t info, uint32_t at, uint32_t first_add) {
+    const uint32_t combo = item_combo(info);
+    const bool member = first_add <= at;  // added by a message at an earlier offset
+    return (uint32_t)(combo_score(combo, member) + 4) | (combo_decodes(combo, member) ? 1u << 12 : 0u) | (combo_is_short(combo) ? 0u : 1u << 13);
+}
 __device__ __forceinline__ void replay_score_body(const ReplayArgs &r) {
     const uint32_t n_items = items_of(r);
     if (blockIdx.x == 0 && threadIdx.x == 0 && r.counters) r.counters[kCntChanged] = 0;  // (k_replay_compare of this round raises it)
@@ -2038,17 +2068,12 @@ __device__ __forceinline__ void replay_score_body(const ReplayArgs &r) {
         uint32_t first = kNever, first_t = kNever;
         if (live) first = r.t_cur[item_value(info)];
         if (live_t) first_t = r.t_cur[item_value(info_t)];
-        auto word = [](uint32_t inf, uint32_t at, uint32_t first_add) {
-            const uint32_t combo = item_combo(inf);
-            const bool member = first_add <= at;  // added by a message at an earlier offset
-            return (uint32_t)(combo_score(combo, member) + 4) | (combo_decodes(combo, member) ? 1u << 12 : 0u) | (combo_is_short(combo) ? 0u : 1u << 13);
-        };
         if (own) r.acc[i] = 0;
         s_g[t] = own ? g : kNever;
-        s_w[t] = live ? word(info, g, first) : 0u;
+        s_w[t] = live ? score_word(info, g, first) : 0u;
         if (t < 4) {
             s_g[kThreads + t] = tail ? g_t : kNever;
-            s_w[kThreads + t] = live_t ? word(info_t, g_t, first_t) : 0u;
+            s_w[kThreads + t] = live_t ? score_word(info_t, g_t, first_t) : 0u;
         }
         __syncthreads();
         if (own) {
@@ -2126,6 +2151,88 @@ __device__ __forceinline__ void replay_walk_body(const ReplayArgs &r) {
             r.acc_rank[i + ((c >> 16) & 15u)] = accepted + (uint32_t)__popcll(taken & ((1ull << pos) - 1ull));  // k_replay_emit: the record's place = the block's base + this
         }
         accepted += (uint32_t)__popcll(taken);
+    }
+    if (lane == 0) r.blk_counts[b] = accepted;
+}
+
+// The first round of a chain: k_replay_score's work inside the walk (one launch and its trips to memory less: 23 us per Gsample).  The
+// wavefront scores its block's items 64 at a time -- key, info, then the table's entry -- and the offsets' first lanes read their up
+// to four followers' results with lane shuffles; the last four lanes of a batch only serve as followers and come again as lanes 0-3 of
+// the next one (batches advance by 60 items), unless the batch reaches the block's end.  r.cand is not used.
+__device__ __forceinline__ void replay_walk_scored_body(const ReplayArgs &r) {
+    __shared__ uint2 cand_q[kThreads / 64][64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * (kThreads / 64) + wave;
+    if (b >= r.nblocks) return;  // whole wavefronts leave; no workgroup barrier below
+    const uint32_t lo = r.blk_start[b], hi = r.blk_start[b + 1];
+    for (uint32_t i = lo + lane; i < hi; i += 64) r.acc[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the winners' entries are written by other lanes further down: after these)
+    uint32_t next_j = 0, accepted = 0, prev_g = kNever;  // wave-uniform
+    uint64_t key_next = 0;
+    uint32_t info_next = 0;
+    if (lo + lane < hi) {
+        key_next = r.keys[lo + lane];
+        info_next = r.info[lo + lane];
+    }
+    for (uint32_t base = lo; base < hi;) {
+        const bool last = base + 64 >= hi;
+        const uint32_t step = last ? 64u : 60u, i = base + lane;
+        const bool own = i < hi;
+        const uint64_t key = key_next;
+        const uint32_t info = info_next, g = (uint32_t)(key >> 3);
+        const bool live = own && item_combo(info) != kComboMarker;
+        uint32_t first_add = kNever;
+        if (live) first_add = r.t_cur[item_value(info)];
+        key_next = 0;
+        info_next = 0;
+        if (i + step < hi) {  // the next batch's items, while this one is scored and chained
+            key_next = r.keys[i + step];
+            info_next = r.info[i + step];
+        }
+        const uint32_t w = live ? score_word(info, g, first_add) : 0u, gg = own ? g : kNever;
+        const uint32_t g_up = (uint32_t)__shfl_up((int)gg, 1, 64);
+        const bool starts = own && (lane ? g_up != g : prev_g != g);
+        const bool mine = starts && (lane < 60 || last);
+        int best = -3;
+        uint32_t best_off = 0, best_w = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < 5; ++d) {
+            const uint32_t src = (lane + d) & 63u;
+            const uint32_t gd = d ? (uint32_t)__shfl((int)gg, (int)src, 64) : gg, wd = d ? (uint32_t)__shfl((int)w, (int)src, 64) : w;
+            const int sc = (int)(wd & 0xfffu) - 4;
+            if (mine && lane + d < 64 && gd == g && wd != 0 && sc > best) {  // (an offset's items are neighbours: behind the first other offset nothing matches)
+                best = sc;
+                best_off = d;
+                best_w = wd;
+            }
+        }
+        uint32_t c = 0;
+        if (best >= 0 && (best_w & (1u << 12))) c = ((uint32_t)best + 1u) | (best_off << 16) | ((best_w >> 13) << 20);
+        prev_g = (uint32_t)__builtin_amdgcn_readlane((int)gg, 59);  // (used when the next batch starts at lane 60's item)
+        const bool cand = c != 0;
+        const uint64_t cm = __ballot(cand);
+        const uint32_t pos = lanes_below(cm), nc = (uint32_t)__popcll(cm);
+        wave_sync();
+        if (cand) cand_q[wave][pos] = make_uint2(g, g + ((c >> 20) ? 268u : 134u) + 1);
+        wave_sync();
+        uint64_t taken = 0;  // by queue position
+        for (uint32_t k0 = 0; k0 < nc; k0 += 8) {  // every lane runs the same chain
+            uint2 q[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) q[u] = cand_q[wave][(k0 + u) & 63u];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const bool take = k0 + u < nc && q[u].x >= next_j;
+                next_j = take ? q[u].y : next_j;
+                taken |= (uint64_t)take << (k0 + u);
+            }
+        }
+        if (cand && ((taken >> pos) & 1ull)) {
+            r.acc[i + ((c >> 16) & 15u)] = c & 0xffffu;
+            r.acc_rank[i + ((c >> 16) & 15u)] = accepted + (uint32_t)__popcll(taken & ((1ull << pos) - 1ull));
+        }
+        accepted += (uint32_t)__popcll(taken);
+        base += step;
     }
     if (lane == 0) r.blk_counts[b] = accepted;
 }
@@ -2750,6 +2857,7 @@ __global__ __launch_bounds__(kThreads) void k_prune_write(const BatchArgs a) { p
 __global__ __launch_bounds__(kThreads) void k_replay_bounds(const ReplayArgs r) { replay_bounds_body(r, blockIdx.x, gridDim.x, kThreads); }
 __global__ __launch_bounds__(kThreads) void k_replay_score(const ReplayArgs r) { replay_score_body(r); }
 __global__ __launch_bounds__(kThreads) void k_replay_walk(const ReplayArgs r) { replay_walk_body(r); }
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_replay_walk_scored(const ReplayArgs r) { replay_walk_scored_body(r); }
 __global__ __launch_bounds__(1024) void k_replay_blkbase(const ReplayArgs r) { replay_blkbase_body(r); }
 template <bool SEED>
 __global__ __launch_bounds__(kMinThreads) void k_replay_table_min(const ReplayArgs r) { replay_table_min_body<SEED>(r, gridDim.x); }
@@ -2827,6 +2935,10 @@ __global__ __launch_bounds__(kThreads) void k_replay_score_many(const ChainArgs 
 __global__ __launch_bounds__(kThreads) void k_replay_walk_many(const ChainArgs *__restrict__ m) {
     const ChainArgs &c = m[blockIdx.y];
     if (!chain_idle(c)) replay_walk_body(c.r);
+}
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_replay_walk_scored_many(const ChainArgs *__restrict__ m) {
+    const ChainArgs &c = m[blockIdx.y];
+    if (!chain_idle(c)) replay_walk_scored_body(c.r);
 }
 __global__ __launch_bounds__(kThreads) void k_replay_compare_many(const ChainArgs *__restrict__ m) {
     const ChainArgs &c = m[blockIdx.y];
@@ -3978,8 +4090,8 @@ hipError_t launch_replay_first_round(const BatchArgs &a, const ReplayArgs &r, hi
         const hipError_t e = launch_replay_iteration(a, r, s);
         return e != hipSuccess ? e : launch_replay_select(a, r, nullptr, 0, s);
     }
-    if (r.n_items) hipLaunchKernelGGL(k_replay_score, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);  // (clears counters[kCntChanged])
-    hipLaunchKernelGGL(k_replay_walk, dim3((r.nblocks + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, s, r);
+    // (counters[kCntChanged] was cleared by the bounds kernel in front; the list kernel raises it)
+    hipLaunchKernelGGL(k_replay_walk_scored, dim3((r.nblocks + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, s, r);
     hipLaunchKernelGGL(k_replay_blkbase, dim3(1), dim3(1024), 0, s, r);
     if (r.n_items) hipLaunchKernelGGL(k_replay_list<true>, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, a.counters);
     return hipGetLastError();
@@ -4062,8 +4174,12 @@ hipError_t launch_chain_replay_many(int fmt, const ChainArgs *args_dev, const Ch
         hipLaunchKernelGGL(k_replay_seed_bounds_many, dim3(runs + bounds_blocks(d.max_items), d.nch), dim3(kMinThreads), 0, s, args_dev, runs);
     else
         hipLaunchKernelGGL(k_replay_bounds_many, dim3(items1, d.nch), dim3(kThreads), 0, s, args_dev);
-    hipLaunchKernelGGL(k_replay_score_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
-    hipLaunchKernelGGL(k_replay_walk_many, dim3((d.max_nblocks + kThreads / 64 - 1) / (kThreads / 64), d.nch), dim3(kThreads), 0, s, args_dev);
+    if (list_checks()) {
+        hipLaunchKernelGGL(k_replay_walk_scored_many, dim3((d.max_nblocks + kThreads / 64 - 1) / (kThreads / 64), d.nch), dim3(kThreads), 0, s, args_dev);
+    } else {
+        hipLaunchKernelGGL(k_replay_score_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
+        hipLaunchKernelGGL(k_replay_walk_many, dim3((d.max_nblocks + kThreads / 64 - 1) / (kThreads / 64), d.nch), dim3(kThreads), 0, s, args_dev);
+    }
     if (!list_checks()) {
         hipLaunchKernelGGL(k_replay_table_min_many<false>, dim3(runs, d.nch), dim3(kMinThreads), 0, s, args_dev);
         hipLaunchKernelGGL(k_replay_compare_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
