@@ -2155,88 +2155,6 @@ __device__ __forceinline__ void replay_walk_body(const ReplayArgs &r) {
     if (lane == 0) r.blk_counts[b] = accepted;
 }
 
-// The first round of a chain: k_replay_score's work inside the walk (one launch and its trips to memory less: 23 us per Gsample).  The
-// wavefront scores its block's items 64 at a time -- key, info, then the table's entry -- and the offsets' first lanes read their up
-// to four followers' results with lane shuffles; the last four lanes of a batch only serve as followers and come again as lanes 0-3 of
-// the next one (batches advance by 60 items), unless the batch reaches the block's end.  r.cand is not used.
-__device__ __forceinline__ void replay_walk_scored_body(const ReplayArgs &r) {
-    __shared__ uint2 cand_q[kThreads / 64][64];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t b = blockIdx.x * (kThreads / 64) + wave;
-    if (b >= r.nblocks) return;  // whole wavefronts leave; no workgroup barrier below
-    const uint32_t lo = r.blk_start[b], hi = r.blk_start[b + 1];
-    for (uint32_t i = lo + lane; i < hi; i += 64) r.acc[i] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the winners' entries are written by other lanes further down: after these)
-    uint32_t next_j = 0, accepted = 0, prev_g = kNever;  // wave-uniform
-    uint64_t key_next = 0;
-    uint32_t info_next = 0;
-    if (lo + lane < hi) {
-        key_next = r.keys[lo + lane];
-        info_next = r.info[lo + lane];
-    }
-    for (uint32_t base = lo; base < hi;) {
-        const bool last = base + 64 >= hi;
-        const uint32_t step = last ? 64u : 60u, i = base + lane;
-        const bool own = i < hi;
-        const uint64_t key = key_next;
-        const uint32_t info = info_next, g = (uint32_t)(key >> 3);
-        const bool live = own && item_combo(info) != kComboMarker;
-        uint32_t first_add = kNever;
-        if (live) first_add = r.t_cur[item_value(info)];
-        key_next = 0;
-        info_next = 0;
-        if (i + step < hi) {  // the next batch's items, while this one is scored and chained
-            key_next = r.keys[i + step];
-            info_next = r.info[i + step];
-        }
-        const uint32_t w = live ? score_word(info, g, first_add) : 0u, gg = own ? g : kNever;
-        const uint32_t g_up = (uint32_t)__shfl_up((int)gg, 1, 64);
-        const bool starts = own && (lane ? g_up != g : prev_g != g);
-        const bool mine = starts && (lane < 60 || last);
-        int best = -3;
-        uint32_t best_off = 0, best_w = 0;
-#pragma unroll
-        for (uint32_t d = 0; d < 5; ++d) {
-            const uint32_t src = (lane + d) & 63u;
-            const uint32_t gd = d ? (uint32_t)__shfl((int)gg, (int)src, 64) : gg, wd = d ? (uint32_t)__shfl((int)w, (int)src, 64) : w;
-            const int sc = (int)(wd & 0xfffu) - 4;
-            if (mine && lane + d < 64 && gd == g && wd != 0 && sc > best) {  // (an offset's items are neighbours: behind the first other offset nothing matches)
-                best = sc;
-                best_off = d;
-                best_w = wd;
-            }
-        }
-        uint32_t c = 0;
-        if (best >= 0 && (best_w & (1u << 12))) c = ((uint32_t)best + 1u) | (best_off << 16) | ((best_w >> 13) << 20);
-        prev_g = (uint32_t)__builtin_amdgcn_readlane((int)gg, 59);  // (used when the next batch starts at lane 60's item)
-        const bool cand = c != 0;
-        const uint64_t cm = __ballot(cand);
-        const uint32_t pos = lanes_below(cm), nc = (uint32_t)__popcll(cm);
-        wave_sync();
-        if (cand) cand_q[wave][pos] = make_uint2(g, g + ((c >> 20) ? 268u : 134u) + 1);
-        wave_sync();
-        uint64_t taken = 0;  // by queue position
-        for (uint32_t k0 = 0; k0 < nc; k0 += 8) {  // every lane runs the same chain
-            uint2 q[8];
-#pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) q[u] = cand_q[wave][(k0 + u) & 63u];
-#pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) {
-                const bool take = k0 + u < nc && q[u].x >= next_j;
-                next_j = take ? q[u].y : next_j;
-                taken |= (uint64_t)take << (k0 + u);
-            }
-        }
-        if (cand && ((taken >> pos) & 1ull)) {
-            r.acc[i + ((c >> 16) & 15u)] = c & 0xffffu;
-            r.acc_rank[i + ((c >> 16) & 15u)] = accepted + (uint32_t)__popcll(taken & ((1ull << pos) - 1ull));
-        }
-        accepted += (uint32_t)__popcll(taken);
-        base += step;
-    }
-    if (lane == 0) r.blk_counts[b] = accepted;
-}
-
 // accepted messages before every 131072-sample block (blk_base[nblocks] = all of the batch's, also to counters[kCntAccepted])
 __device__ __forceinline__ void replay_blkbase_body(const ReplayArgs &r) {
     __shared__ uint32_t part[1024];
@@ -2857,7 +2775,6 @@ __global__ __launch_bounds__(kThreads) void k_prune_write(const BatchArgs a) { p
 __global__ __launch_bounds__(kThreads) void k_replay_bounds(const ReplayArgs r) { replay_bounds_body(r, blockIdx.x, gridDim.x, kThreads); }
 __global__ __launch_bounds__(kThreads) void k_replay_score(const ReplayArgs r) { replay_score_body(r); }
 __global__ __launch_bounds__(kThreads) void k_replay_walk(const ReplayArgs r) { replay_walk_body(r); }
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_replay_walk_scored(const ReplayArgs r) { replay_walk_scored_body(r); }
 __global__ __launch_bounds__(1024) void k_replay_blkbase(const ReplayArgs r) { replay_blkbase_body(r); }
 template <bool SEED>
 __global__ __launch_bounds__(kMinThreads) void k_replay_table_min(const ReplayArgs r) { replay_table_min_body<SEED>(r, gridDim.x); }
@@ -2935,10 +2852,6 @@ __global__ __launch_bounds__(kThreads) void k_replay_score_many(const ChainArgs 
 __global__ __launch_bounds__(kThreads) void k_replay_walk_many(const ChainArgs *__restrict__ m) {
     const ChainArgs &c = m[blockIdx.y];
     if (!chain_idle(c)) replay_walk_body(c.r);
-}
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_replay_walk_scored_many(const ChainArgs *__restrict__ m) {
-    const ChainArgs &c = m[blockIdx.y];
-    if (!chain_idle(c)) replay_walk_scored_body(c.r);
 }
 __global__ __launch_bounds__(kThreads) void k_replay_compare_many(const ChainArgs *__restrict__ m) {
     const ChainArgs &c = m[blockIdx.y];
@@ -4090,8 +4003,8 @@ hipError_t launch_replay_first_round(const BatchArgs &a, const ReplayArgs &r, hi
         const hipError_t e = launch_replay_iteration(a, r, s);
         return e != hipSuccess ? e : launch_replay_select(a, r, nullptr, 0, s);
     }
-    // (counters[kCntChanged] was cleared by the bounds kernel in front; the list kernel raises it)
-    hipLaunchKernelGGL(k_replay_walk_scored, dim3((r.nblocks + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, s, r);
+    if (r.n_items) hipLaunchKernelGGL(k_replay_score, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r);
+    hipLaunchKernelGGL(k_replay_walk, dim3((r.nblocks + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, s, r);
     hipLaunchKernelGGL(k_replay_blkbase, dim3(1), dim3(1024), 0, s, r);
     if (r.n_items) hipLaunchKernelGGL(k_replay_list<true>, dim3(item_grid(r.n_items)), dim3(kThreads), 0, s, r, a.counters);
     return hipGetLastError();
@@ -4174,12 +4087,8 @@ hipError_t launch_chain_replay_many(int fmt, const ChainArgs *args_dev, const Ch
         hipLaunchKernelGGL(k_replay_seed_bounds_many, dim3(runs + bounds_blocks(d.max_items), d.nch), dim3(kMinThreads), 0, s, args_dev, runs);
     else
         hipLaunchKernelGGL(k_replay_bounds_many, dim3(items1, d.nch), dim3(kThreads), 0, s, args_dev);
-    if (list_checks()) {
-        hipLaunchKernelGGL(k_replay_walk_scored_many, dim3((d.max_nblocks + kThreads / 64 - 1) / (kThreads / 64), d.nch), dim3(kThreads), 0, s, args_dev);
-    } else {
-        hipLaunchKernelGGL(k_replay_score_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
-        hipLaunchKernelGGL(k_replay_walk_many, dim3((d.max_nblocks + kThreads / 64 - 1) / (kThreads / 64), d.nch), dim3(kThreads), 0, s, args_dev);
-    }
+    hipLaunchKernelGGL(k_replay_score_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
+    hipLaunchKernelGGL(k_replay_walk_many, dim3((d.max_nblocks + kThreads / 64 - 1) / (kThreads / 64), d.nch), dim3(kThreads), 0, s, args_dev);
     if (!list_checks()) {
         hipLaunchKernelGGL(k_replay_table_min_many<false>, dim3(runs, d.nch), dim3(kMinThreads), 0, s, args_dev);
         hipLaunchKernelGGL(k_replay_compare_many, dim3(items, d.nch), dim3(kThreads), 0, s, args_dev);
