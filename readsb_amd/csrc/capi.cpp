@@ -1132,9 +1132,13 @@ int CollectRun::replay() {
     }
 #endif
     if (cnt[kCntOverflow] || cnt[kCntSurvItems] > c->surv_item_cap || cnt[kCntAc] > c->ac_cap) {
-        char buf[200];
-        std::snprintf(buf, sizeof(buf), "device queue overflow: %u item regions, kept items %u/%u, modeac %u/%u (lower rsb_config.queue_div)",
-                      cnt[kCntOverflow], cnt[kCntSurvItems], c->surv_item_cap, cnt[kCntAc], c->ac_cap);
+        char buf[240];
+        if (cnt[kCntOverflow] >= kPruneStallUnit)
+            std::snprintf(buf, sizeof(buf), "ordered prune: %u tile(s) gave up waiting for the tiles before them (a stalled device queue?); the batch is lost",
+                          cnt[kCntOverflow] / kPruneStallUnit);
+        else
+            std::snprintf(buf, sizeof(buf), "device queue overflow: %u item regions, kept items %u/%u, modeac %u/%u (lower rsb_config.queue_div)",
+                          cnt[kCntOverflow], cnt[kCntSurvItems], c->surv_item_cap, cnt[kCntAc], c->ac_cap);
         c->err = buf;
         c->finished = true;
         return RSB_EOVERFLOW;

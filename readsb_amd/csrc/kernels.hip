@@ -1712,12 +1712,13 @@ __device__ __forceinline__ void prune_write_body(const BatchArgs &a) {
 // A tile's number is its workgroup's: workgroups start in ascending order (per XCD, which take them in turn), so the lowest unfinished
 // tile is always resident and waits for nobody.  (Numbers from a counter, as rocPRIM's look-back scan takes them, cost more than the
 // whole prune: 6000 atomics on one address, one after the other.)  The wait is bounded all the same: a tile that gives up raises
-// kCntOverflow, the batch ends with RSB_EOVERFLOW instead of a hung queue.
+// kCntOverflow by kPruneStallUnit, the batch ends with RSB_EOVERFLOW (and a message that says so) instead of a hung queue.
 #ifndef RSB_TILE_THREADS
 #define RSB_TILE_THREADS 1024
 #endif
 constexpr int kTileThreads = RSB_TILE_THREADS, kTileChunks = kTileThreads / 8;
 constexpr uint64_t kTileOwn = 1ull << 62, kTileTotal = 2ull << 62;
+constexpr uint32_t kTileGaveUp = kPruneStallUnit;  // what a tile that gave up adds to kCntOverflow (the host tells it from full item regions)
 #ifndef RSB_TILE_LOADS
 #define RSB_TILE_LOADS 4
 #endif
@@ -1834,7 +1835,7 @@ __device__ __forceinline__ void prune_onepass_body(const BatchArgs &a) {
         }
         if (lane == 0) {
             __hip_atomic_store(&status[tile], kTileTotal | tile_pack(run_kept + own_kept, run_all + own_all), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (gave_up) atomicAdd(&a.counters[kCntOverflow], 1u);
+            if (gave_up) atomicAdd(&a.counters[kCntOverflow], kTileGaveUp);
             if (tile == ntiles - 1) {
                 a.counters[kCntSurvItems] = run_kept + own_kept;
                 a.counters[kCntItemsTotal] = run_all + own_all;

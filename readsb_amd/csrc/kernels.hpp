@@ -156,6 +156,8 @@ struct ReplayArgs {
     uint32_t host_cap;       // ... which holds this many
 };
 constexpr uint32_t kNever = 0xffffffffu;
+// counters[kCntOverflow]: full item regions in the low 16 bits; the one-pass prune adds this per tile that gave up waiting for the tiles before it
+constexpr uint32_t kPruneStallUnit = 1u << 16;
 
 // One channel's batch in a launch that takes the batches of several channels (rsb_collect_many)
 struct ChainArgs {
