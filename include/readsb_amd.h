@@ -42,7 +42,7 @@ enum {
     RSB_EINVAL = -1,   /* bad argument / unsupported combination */
     RSB_ENODEV = -2,   /* no HIP device, or a HIP call failed */
     RSB_ENOMEM = -3,
-    RSB_EOVERFLOW = -4,/* a device queue overflowed (raise rsb_config.queue_div); no partial results */
+    RSB_EOVERFLOW = -4,/* a device queue overflowed (raise rsb_config.queue_div), or the prune's bounded wait ran out (rsb_last_error says which); no partial results */
     RSB_ESTATE = -5    /* call sequence error (collect without submit, unaligned stream position...) */
 };
 
